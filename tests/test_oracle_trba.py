@@ -1,0 +1,45 @@
+"""Oracle TRBA restatement vs golden vectors generated from the reference's model files."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from manuscript_ocr_amd import synth
+from oracle import trba_model as otm
+
+
+def _net(seed):
+    net = otm.TRBANet(194, 256)
+    net.load_state_dict(otm.synth_trba_state_dict(194, 256, seed=seed), strict=True)
+    return net.eval()
+
+
+@pytest.mark.parametrize("tag,B,h,w", [("b4_32x100", 4, 32, 100), ("b2_64x256", 2, 64, 256)])
+def test_trba_golden(golden_dir, tag, B, h, w):
+    g = np.load(os.path.join(golden_dir, "trba.npz"))
+    seed = int(g["seed"])
+    net = _net(seed)
+    crops = synth.synth_crops(seed + 2, B, h, w)
+    x = torch.from_numpy(((crops.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
+    with torch.no_grad():
+        f = net.cnn(x)
+        enc = net.encode(x)
+        gl, gi = net(x, max_len=25, mode="greedy")
+        bl, bi = net(x, max_len=25, mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
+        bl5, bi5 = net(x, max_len=25, mode="beam", beam_size=5, alpha=0.0, temperature=1.0)
+    # same torch ops in the same order as the reference -> bit-exact
+    assert np.array_equal(f.numpy(), g[f"{tag}_cnn"])
+    assert np.array_equal(enc.numpy(), g[f"{tag}_enc"])
+    for got_l, got_i, key in ((gl, gi, "greedy"), (bl, bi, "beam"), (bl5, bi5, "beam5")):
+        assert np.array_equal(got_i.numpy(), g[f"{tag}_{key}_ids"]), key
+        assert np.array_equal(got_l.numpy(), g[f"{tag}_{key}_logits"]), key
+
+
+def test_charset_and_decode_tokens():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "manuscript_ocr_amd",
+                        "recognizers", "_trba", "configs", "charset.txt")
+    itos, stoi = otm.load_charset(path)
+    assert len(itos) == 194 and itos[:4] == ["<PAD>", "<SOS>", "<EOS>", " "] and "<BLANK>" not in stoi
+    assert otm.decode_tokens([4, 0, 5, 2, 6], itos, 0, 2, None) == "ab"
+    assert otm.decode_tokens([], itos, 0, 2, None) == ""
