@@ -1,0 +1,157 @@
+/* msocr.h — C ABI of libmsocr.so, the MI355X (gfx950) hot path of manuscript-ocr.
+ *
+ * The reference (olegiy/manuscript-ocr) has no FFI: its boundary is the Python
+ * plugin API (Pipeline / EAST / TRBA).  This header is the INNER native boundary
+ * that the Python host in manuscript_ocr_amd/ binds with ctypes; every entry
+ * point names the reference code it replaces (paths relative to
+ * /root/reference/src/manuscript/).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
+ *     stream-ordered, allocates nothing and never synchronises (graph-capturable);
+ *   - activations are NHWC; `dtype` selects the storage/MFMA input type
+ *     (MSOCR_F32: v_mfma_f32_32x32x2_f32, exact f32; MSOCR_BF16:
+ *     v_mfma_f32_32x32x16_bf16, f32 accumulate);
+ *   - return value: 0 = ok, negative = MSOCR_E_* (nothing was launched).
+ */
+#ifndef MSOCR_H
+#define MSOCR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSOCR_F32 0
+#define MSOCR_BF16 1
+
+#define MSOCR_OK 0
+#define MSOCR_E_ARG (-1)     /* bad argument / unsupported shape */
+#define MSOCR_E_LAUNCH (-2)  /* hipLaunch failed */
+#define MSOCR_E_NOGPU (-3)
+
+/* flags for msocr_conv2d */
+#define MSOCR_CONV_RELU 1u
+#define MSOCR_CONV_RESIDUAL 2u /* out = act(conv + bias + residual) */
+
+typedef struct msocr_conv_desc {
+  int32_t dtype;                 /* MSOCR_F32 | MSOCR_BF16 (input, weight, residual, output) */
+  int32_t N, H, W, Cin;          /* input extent; Cin = channels reduced per tap (multiple of 32 f32 / 32 bf16) */
+  int64_t in_sN, in_sH, in_sW;   /* input strides in ELEMENTS (channel stride is 1) */
+  int32_t KH, KW, stride_h, stride_w, pad_h, pad_w;
+  int32_t Ho, Wo, Cout;          /* Cout multiple of 32 */
+  int64_t out_ld;                /* elements between consecutive output pixels (>= Cout) */
+  int64_t res_ld;                /* same for the residual tensor */
+  uint32_t flags;
+} msocr_conv_desc;
+
+/* Implicit-GEMM convolution on MFMA: out[n,ho,wo,co] = act(sum_{kh,kw,c} in[n,ho*sh-ph+kh,wo*sw-pw+kw,c] *
+ * w[co,kh,kw,c] + bias[co] (+ residual)).  weight layout [Cout][KH][KW][Cin] (dtype), bias f32 with BatchNorm
+ * folded in by the host.  Replaces every nn.Conv2d+BatchNorm2d(+ReLU)(+add) of
+ *   detectors/_east/east.py:13-30,56-67,96-105 (torchvision ResNet-50 Bottlenecks, DecoderBlock) and
+ *   recognizers/_trba/model/seresnet31.py:37-45,81-89,129-136,150-155. */
+int msocr_conv2d(const msocr_conv_desc* d, const void* in, const void* weight, const float* bias,
+                 const void* residual, void* out, void* stream);
+
+/* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->4 inside a zero canvas
+ * out[N][Hp][Wp][4], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
+ *   mode 0: EAST ToTensor+Normalize, detectors/_east/infer.py:127-132,305  -> (x/255 - .5)/.5
+ *   mode 1: TRBA A.Normalize(.5,.5,max 255), recognizers/_trba/data/transforms.py:185-193 -> (x-127.5)*f32(1/127.5) */
+int msocr_normalize_u8(const uint8_t* src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, int mode,
+                       int dtype, void* out, void* stream);
+
+/* cv2.resize(img,(dw,dh)) INTER_LINEAR for u8 HxWx3 (OpenCV 11-bit fixed point), batched.
+ * Replaces detectors/_east/infer.py:304 (restated from OpenCV, parity unpinned). */
+int msocr_resize_linear_u8(const uint8_t* src, int N, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
+
+/* MaxPool2d(k, stride=s, padding=p) on NHWC.  (torchvision resnet maxpool 3/2/1; seresnet31.py:88 2/2/0) */
+int msocr_maxpool2d(const void* in, int N, int H, int W, int C, int64_t in_ld, int k, int s, int p, int dtype,
+                    void* out, int Ho, int Wo, int64_t out_ld, void* stream);
+
+/* F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) written into the first C channels of a
+ * concat buffer (out_ld >= C): fuses the torch.cat of detectors/_east/east.py:87-92. */
+int msocr_upsample2x_bilinear(const void* in, int N, int H, int W, int C, int64_t in_ld, int dtype, void* out,
+                              int64_t out_ld, void* stream);
+
+/* OutputHead (east.py:96-105): score = sigmoid(w_s . x + b_s), geo = W_g x + b_g from the 32-channel h1.
+ * w9 = [9][32] f32 (row 0 score, rows 1..8 geo), b9 = [9] f32.  score_out [N][H][W] f32, geo_out [N][H][W][8] f32. */
+int msocr_east_head(const void* h1, int64_t npix, int64_t in_ld, int dtype, const float* w9, const float* b9,
+                    float* score_out, float* geo_out, void* stream);
+
+/* decode_quads_from_maps (detectors/_east/utils.py:328-381), batched over pages: threshold (strict >),
+ * quantise to q x q cells, unique in (y,x) order, decode 4 vertices + score at the cell centre.
+ * cand_out [N][max_cand][9] f32, count_out [N] int32 (clamped to max_cand; overflow flag in bit 31). */
+int msocr_east_decode(const float* score, const float* geo, int N, int H, int W, float thresh, float scale,
+                      int quant, float* cand_out, int32_t* count_out, int max_cand, void* stream);
+
+/* locality_aware_nms (detectors/_east/lanms.py:156-207 incl. standard_nms :133-153 and the fp64 geometry :7-130),
+ * batched over pages.  cand [N][max_cand][9] f32 + counts from msocr_east_decode; boxes_out [N][max_cand][9] f32,
+ * nbox_out [N] int32.  workspace: msocr_lanms_workspace_bytes(N, max_cand) bytes. */
+int64_t msocr_lanms_workspace_bytes(int N, int max_cand);
+int msocr_east_lanms(const float* cand, const int32_t* counts, int N, int max_cand, double iou_thr, float* boxes_out,
+                     int32_t* nbox_out, void* workspace, void* stream);
+
+/* ---- TRBA ---------------------------------------------------------------------------------------------- */
+
+/* SELayer (recognizers/_trba/model/seresnet31.py:5-20) fused with the residual tail of SEBasicBlock.forward
+ * (:61-66): out = relu(x * sigmoid(W2 relu(W1 mean_hw(x))) + identity).  x, identity, out: [N][HW][C] (ld = C).
+ * w1 [C/16][C] f32, w2 [C][C/16] f32.  gate_ws: [N][C] f32 scratch. */
+int msocr_se_residual(const void* x, const void* identity, int N, int HW, int C, int dtype, const float* w1,
+                      const float* w2, float* gate_ws, void* out, void* stream);
+
+/* AdaptiveAvgPool2d((1,None)) + squeeze + permute (recognizers/_trba/model/model.py:388-390):
+ * [N][H][W][C] (dtype) -> [N][W][C] f32. */
+int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int dtype, float* out, void* stream);
+
+/* One bidirectional LSTM layer + Linear (BidirectionalLSTM.forward, model/model.py:9-21).
+ * xproj [B][T][2][4H] f32 = x W_ih^T + b_ih + b_hh for both directions (an msocr_conv2d 1x1 / GEMM);
+ * w_hh_t [2][H][4H] f32 (transposed, gate order i,f,g,o); hcat_out [B][T][2H] f32. */
+int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out,
+                           void* stream);
+
+/* Dense f32 GEMM-with-bias on VALU for the small linears: out[M][N] = x[M][K] W^T[K][N] + b. w_t = [K][N]. */
+int msocr_linear_f32(const float* x, const float* w_t, const float* bias, int M, int K, int N, float* out,
+                     void* stream);
+
+typedef struct msocr_attn_weights {
+  const float* h2h_wt;   /* [H][H]   h2h.weight^T */
+  const float* h2h_b;    /* [H] */
+  const float* score_w;  /* [H] */
+  const float* wih_ctx_t;/* [H][4H]  rnn.weight_ih[:, :H]^T */
+  const float* wih_tok;  /* [V][4H]  rnn.weight_ih[:, H:]^T (one-hot matmul == row gather) */
+  const float* whh_t;    /* [H][4H] */
+  const float* b_gates;  /* [4H] b_ih + b_hh */
+  const float* gen_wt;   /* [H][V]  generator.weight^T */
+  const float* gen_b;    /* [V] */
+} msocr_attn_weights;
+
+/* Attention decode (model/model.py:34-46 cell, :227-259 greedy, :92-225 beam), one workgroup per batch row,
+ * whole loop in one launch.  batch_H, proj_H: [B][T][H] f32 (proj_H = i2h(batch_H), hoisted).
+ * greedy: steps = max_len+1; logits_out [B][steps][V], ids_out [B][steps] int32.
+ * beam:   steps = max_len; outputs are the best beam's path (temperature-scaled logits), plus
+ *         fin_step_out [B] = first step index after which every beam of the row is finished (or steps).
+ * The reference's batch-level early break (model.py:215,254) is applied by the host from these. */
+int msocr_attn_greedy(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
+                      int V, int steps, int sos_id, int eos_id, int blank_id, float* logits_out, int32_t* ids_out,
+                      void* stream);
+int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
+                    int V, int steps, int beam, float alpha, float temperature, int sos_id, int eos_id, int blank_id,
+                    float* logits_out, int32_t* ids_out, int32_t* fin_step_out, void* workspace, void* stream);
+int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, int V);
+
+/* u8 crops -> normalised TRBA batch (ResizeAndPadA+Normalize, recognizers/_trba/data/transforms.py:62-120,185-193)
+ * from boxes of a device-resident page: next-round item; round 1 preprocesses crops on the host. */
+
+/* f32 <-> bf16 / layout helpers */
+int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int W, int dtype, void* out, int64_t out_ld,
+                           void* stream);
+int msocr_nhwc_to_nchw_f32(const void* in, int N, int C, int H, int W, int64_t in_ld, int dtype, float* out,
+                           void* stream);
+
+const char* msocr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSOCR_H */

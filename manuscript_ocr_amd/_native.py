@@ -1,0 +1,91 @@
+"""ctypes binding of libmsocr.so (include/msocr.h) — the only door to the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing or fails to load, every
+native op raises.  PyTorch is used only to own device memory and streams; the
+C ABI sees raw pointers and sizes.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsocr.so")
+
+F32, BF16 = 0, 1
+CONV_RELU, CONV_RESIDUAL = 1, 2
+
+c_i32, c_i64, c_u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+c_f32, c_f64, c_vp = ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
+        ("in_sN", c_i64), ("in_sH", c_i64), ("in_sW", c_i64),
+        ("KH", c_i32), ("KW", c_i32), ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32),
+        ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
+        ("out_ld", c_i64), ("res_ld", c_i64), ("flags", c_u32),
+    ]
+
+
+class AttnWeights(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("h2h_wt", "h2h_b", "score_w", "wih_ctx_t", "wih_tok", "whh_t", "b_gates", "gen_wt", "gen_b")]
+
+
+_SIGS = {
+    "msocr_conv2d": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),
+    "msocr_upsample2x_bilinear": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "msocr_east_head": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_east_decode": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "msocr_lanms_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "msocr_east_lanms": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_se_residual": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_mean_over_h": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_bilstm_recurrent": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_linear_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_attn_greedy": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  c_vp, c_vp, c_vp]),
+    "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32,
+                                c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_attn_beam_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "msocr_nchw_f32_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "msocr_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "msocr_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmsocr.so (once).  Fails loudly: the product has no non-HIP path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C manuscript_ocr_amd/csrc`). There is no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in _SIGS if not hasattr(L, name)]
+        if missing:
+            raise NativeError(f"{LIB_PATH} lacks symbols declared in include/msocr.h: {missing}")
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed with code {rc} (-1 bad argument/shape, -2 launch failure)")

@@ -1,0 +1,359 @@
+// conv_igemm.hip — im2col-free implicit-GEMM convolution on MFMA for gfx950 (MI355X).
+//
+// GEMM view: D[M = N*Ho*Wo][Cout] = A[M][K = KH*KW*Cin] * W^T, NHWC activations, weights
+// [Cout][KH][KW][Cin].  Both operands are K-contiguous, so both LDS tiles are [rows][BK]
+// with 16-byte chunks XOR-swizzled by row (ds_read_b128 conflict-free), and one code path
+// serves f32 (v_mfma_f32_32x32x2_f32, exact f32) and bf16 (v_mfma_f32_32x32x16_bf16).
+// A K-tile never straddles a filter tap (Cin % BK == 0), so an A row is one 16-B-aligned
+// contiguous run of the input: plain global_load_dwordx4 with a zero fill for padding.
+// 256 threads = 4 waves, each wave owns a (WM x WN) sub-tile as 32x32 MFMA tiles.
+// Epilogue: accumulators -> LDS -> (bias, residual, ReLU) -> 16-byte coalesced stores.
+//
+// Replaces nn.Conv2d+BatchNorm2d(+ReLU)(+residual add) on the reference hot path:
+//   detectors/_east/east.py:13-30,56-67 ; recognizers/_trba/model/seresnet31.py:37-45,81-89,129-155
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msocr.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct ConvParams {
+  const char* in;
+  const char* w;
+  const float* bias;
+  const char* res;
+  char* out;
+  int N, H, W, Cin;
+  long sN, sH, sW;
+  int KH, KW, SH, SW, PH, PW;
+  int Ho, Wo, Cout;
+  long M;
+  int ktiles, cin_tiles;
+  long Ktot;
+  long out_ld, res_ld;
+  int relu, has_res;
+  int tilesM, tilesN;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<float> {
+  // one 16-byte chunk = 4 consecutive k for this lane's (row, k-half): 4 MFMA 32x32x2 steps
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<__bf16> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    bf16x8 av = __builtin_bit_cast(bf16x8, a);
+    bf16x8 bv = __builtin_bit_cast(bf16x8, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+  }
+};
+
+// BKB = bytes per tile row (64 or 128).  swizzle: 16-B chunk index ^= (row / rows_per_256B) % chunks_per_row
+template <int BKB>
+__device__ __forceinline__ int swz(int row) {
+  constexpr int CPR = BKB / 16;
+  constexpr int RPB = 256 / BKB;
+  return (row / RPB) & (CPR - 1);
+}
+
+template <typename T, int BM, int BN, int BKB, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  constexpr int ES = sizeof(T);
+  constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
+  constexpr int EPC = 16 / ES;   // elements per chunk
+  constexpr int BK = BKB / ES;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int RPP = 256 / CPR;  // tile rows covered per pass of 256 threads
+  constexpr int A_IT = BM / RPP;
+  constexpr int B_IT = (BN + RPP - 1) / RPP;
+  constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // XCD-aware tile mapping: blocks b, b+8, ... share an XCD/L2 -> give each XCD a contiguous
+  // range of logical tiles (all N-tiles of neighbouring M-tiles: shared A rows + 3x3 halos).
+  const int nblk = p.tilesM * p.tilesN;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tilesN;
+  const int tile_m = bid / p.tilesN;
+
+  // ---- per-thread staging coordinates (fixed over the K loop) ----
+  const int chunk = tid % CPR;
+  const int row0 = tid / CPR;
+  long a_base[A_IT];
+  int a_hi0[A_IT], a_wi0[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const long m = (long)tile_m * BM + row0 + i * RPP;
+    if (m < p.M) {
+      const long hw = (long)p.Ho * p.Wo;
+      const int n = (int)(m / hw);
+      const int rem = (int)(m - (long)n * hw);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.SH - p.PH;
+      a_wi0[i] = wo * p.SW - p.PW;
+      a_base[i] = (long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + chunk * EPC;
+    } else {
+      a_hi0[i] = -0x40000000;  // never in range
+      a_wi0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+  const char* b_ptr[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int co = tile_n * BN + row0 + j * RPP;
+    b_ptr[j] = p.w + ((long)co * p.Ktot + chunk * EPC) * ES;
+  }
+
+  u32x4 ra[A_IT], rb[B_IT];
+
+  auto load_tile = [&](int kt) {
+    const int tap = kt / p.cin_tiles;
+    const int c0 = (kt - tap * p.cin_tiles) * BK;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const long koff = (long)kh * p.sH + (long)kw * p.sW + c0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+      const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(p.in + (a_base[i] + koff) * ES);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      if (BN % RPP == 0 || row0 + j * RPP < BN) rb[j] = *reinterpret_cast<const u32x4*>(b_ptr[j] + (long)kt * BKB);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = row0 + i * RPP;
+      *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int row = row0 + j * RPP;
+      if (BN % RPP == 0 || row < BN) *reinterpret_cast<u32x4*>(sb + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int r32 = lane & 31, half = lane >> 5;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < p.ktiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int q = 0; q < CPR / 2; ++q) {
+      const int c = 2 * q + half;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 32 + r32;
+        fa[i] = *reinterpret_cast<const u32x4*>(sa + row * BKB + ((c ^ swz<BKB>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 32 + r32;
+        fb[j] = *reinterpret_cast<const u32x4*>(sb + row * BKB + ((c ^ swz<BKB>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < p.ktiles) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: TM passes of (acc row-block -> LDS [PR][BN] f32 -> bias/residual/ReLU -> 16-B stores) ----
+  constexpr int PR = (BM / WM) * 32;  // tile rows handled per pass
+  float* sc = reinterpret_cast<float*>(smem);
+  constexpr int VPR = BN / EPC;       // 16-B output vectors per tile row
+  constexpr int ROWS_PP = 256 / VPR;  // rows per sweep of 256 threads
+  const int vcol = (tid % VPR) * EPC;
+  const int vrow0 = tid / VPR;
+  const int co = tile_n * BN + vcol;
+  float bias[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) bias[e] = p.bias ? p.bias[co + e] : 0.f;
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lrow = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int col = wn * WN + j * 32 + r32;
+        sc[lrow * BN + col] = acc[i][j][e];
+      }
+    __syncthreads();
+    for (int lr = vrow0; lr < PR; lr += ROWS_PP) {
+      const int trow = (lr >> 5) * WM + i * 32 + (lr & 31);
+      const long m = (long)tile_m * BM + trow;
+      if (m >= p.M) continue;
+      float v[EPC];
+#pragma unroll
+      for (int e4 = 0; e4 < EPC; e4 += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&sc[lr * BN + vcol + e4]);
+        v[e4] = t[0]; v[e4 + 1] = t[1]; v[e4 + 2] = t[2]; v[e4 + 3] = t[3];
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] += bias[e];
+      if (p.has_res) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + (m * p.res_ld + co) * ES);
+        if constexpr (ES == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(rv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((uint16_t)(rv[e >> 1] >> ((e & 1) * 16)));
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      u32x4 o;
+      if constexpr (ES == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+      }
+      *reinterpret_cast<u32x4*>(p.out + (m * p.out_ld + co) * ES) = o;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int BKB, int WM, int WN>
+static int launch_cfg(ConvParams& p, hipStream_t s) {
+  p.tilesM = (int)((p.M + BM - 1) / BM);
+  p.tilesN = p.Cout / BN;
+  constexpr int BK = BKB / (int)sizeof(T);
+  p.cin_tiles = p.Cin / BK;
+  p.ktiles = p.KH * p.KW * p.cin_tiles;
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int EPI = (BM / WM) * 32 * BN * 4;
+  constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr_set = true;
+  }
+  const long nblk = (long)p.tilesM * p.tilesN;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, s, p);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+template <typename T>
+static int launch_typed(ConvParams& p, hipStream_t s) {
+  constexpr int ES = sizeof(T);
+  // row bytes: 128 B when Cin allows (f32: BK 32, bf16: BK 64), else 64 B
+  const bool wide = (p.Cin * ES) % 128 == 0;
+  if (p.Cout % 128 == 0) {
+    return wide ? launch_cfg<T, 128, 128, 128, 64, 64>(p, s) : launch_cfg<T, 128, 128, 64, 64, 64>(p, s);
+  } else if (p.Cout % 64 == 0) {
+    return wide ? launch_cfg<T, 128, 64, 128, 64, 32>(p, s) : launch_cfg<T, 128, 64, 64, 64, 32>(p, s);
+  } else {
+    return wide ? launch_cfg<T, 256, 32, 128, 64, 32>(p, s) : launch_cfg<T, 256, 32, 64, 64, 32>(p, s);
+  }
+}
+
+extern "C" int msocr_conv2d(const msocr_conv_desc* d, const void* in, const void* weight, const float* bias,
+                            const void* residual, void* out, void* stream) {
+  if (!d || !in || !weight || !out) return MSOCR_E_ARG;
+  const int ES = d->dtype == MSOCR_F32 ? 4 : (d->dtype == MSOCR_BF16 ? 2 : 0);
+  if (!ES) return MSOCR_E_ARG;
+  const int EPC = 16 / ES;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0) return MSOCR_E_ARG;
+  if (d->Cin <= 0 || (d->Cin * ES) % 64 != 0) return MSOCR_E_ARG;           // K-tile inside one tap
+  if (d->Cout <= 0 || d->Cout % 32 != 0) return MSOCR_E_ARG;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride_h <= 0 || d->stride_w <= 0) return MSOCR_E_ARG;
+  // 16-byte alignment of every vector access
+  if (d->in_sN % EPC || d->out_ld % EPC || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  // rows/pixels the kernel can touch: hi = ho*sh - ph + kh, wi = wo*sw - pw + kw; every one must start 16-B aligned
+  if (d->in_sH % EPC) {
+    if ((d->stride_h * d->in_sH) % EPC) return MSOCR_E_ARG;
+    for (int kh = 0; kh < d->KH; ++kh)
+      if (((kh - d->pad_h) * d->in_sH) % EPC) return MSOCR_E_ARG;
+  }
+  if (d->in_sW % EPC) {  // e.g. the C=4 stem canvas: pixels are 8 B in bf16, only even pixels are read
+    if ((d->stride_w * d->in_sW) % EPC) return MSOCR_E_ARG;
+    for (int kw = 0; kw < d->KW; ++kw)
+      if (((kw - d->pad_w) * d->in_sW) % EPC) return MSOCR_E_ARG;
+  }
+  if (((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % EPC || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  // output extent must agree with the conv arithmetic (guards the kernel's indexing)
+  if ((d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 < d->Ho || (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1 < d->Wo)
+    return MSOCR_E_ARG;
+
+  ConvParams p;
+  p.in = (const char*)in; p.w = (const char*)weight; p.bias = bias; p.res = (const char*)residual; p.out = (char*)out;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.sN = d->in_sN; p.sH = d->in_sH; p.sW = d->in_sW;
+  p.KH = d->KH; p.KW = d->KW; p.SH = d->stride_h; p.SW = d->stride_w; p.PH = d->pad_h; p.PW = d->pad_w;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.M = (long)d->N * d->Ho * d->Wo;
+  p.Ktot = (long)d->KH * d->KW * d->Cin;
+  p.out_ld = d->out_ld; p.res_ld = d->res_ld;
+  p.relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
+  p.has_res = has_res ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == MSOCR_F32 ? launch_typed<float>(p, s) : launch_typed<__bf16>(p, s);
+}

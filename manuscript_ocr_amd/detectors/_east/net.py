@@ -1,0 +1,158 @@
+"""Device-side EAST network: ResNet-50 trunk + feature-merging decoder + heads on HIP.
+
+Host logic only (weight folding/packing, buffer plumbing, launch order); every FLOP is
+in libmsocr.so.  Mirrors the reference forward
+(/root/reference/src/manuscript/detectors/_east/east.py:135-139) with:
+  * BatchNorm folded into conv weight/bias at load time (eval mode: exact algebra);
+  * NHWC activations, weights [Cout][KH][KW][Cin];
+  * the 7x7/2 stem run as a 7-tap (kh) conv over 32-element rows of a zero-bordered
+    C=4 canvas (kw and c are contiguous in NHWC), so it uses the same MFMA kernel;
+  * torch.cat([upsample(h), f]) fused away: layer taps write straight into the
+    right channel slice of the concat buffer and the x2 upsample fills the left one.
+State-dict keys are the reference's (`backbone.extractor.*`, `decoder.block*`,
+`output_head.*`), loaded non-strictly like east.py:130-133.
+"""
+import torch
+
+from ... import ops
+
+LAYERS = (("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2), ("layer4", 512, 3, 2))
+BN_EPS = 1e-5
+
+
+def fold_bn(w, conv_bias, prefix_bn, sd):
+    """conv (OIHW f32) followed by eval-mode BatchNorm -> (w', b') in f32."""
+    gamma, beta = sd[prefix_bn + ".weight"].float(), sd[prefix_bn + ".bias"].float()
+    mean, var = sd[prefix_bn + ".running_mean"].float(), sd[prefix_bn + ".running_var"].float()
+    s = gamma / torch.sqrt(var + BN_EPS)
+    w2 = w.float() * s.view(-1, 1, 1, 1)
+    b2 = beta - mean * s
+    if conv_bias is not None:
+        b2 = b2 + conv_bias.float() * s
+    return w2, b2
+
+
+def to_khwc(w, dtype, device):
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device)
+
+
+def pack_stem_weight(w, cin_pad):
+    """OIHW stem weight (C=3) -> [Cout][KH][1][cin_pad] with element kw*4+c = w[co,c,kh,kw], zeros elsewhere."""
+    Cout, C, KH, KW = w.shape
+    assert C <= 4 and KW * 4 <= cin_pad
+    taps = torch.zeros(Cout, KH, KW, 4, dtype=torch.float32)
+    taps[..., :C] = w.float().permute(0, 2, 3, 1)
+    out = torch.zeros(Cout, KH, 1, cin_pad, dtype=torch.float32)
+    out[:, :, 0, : KW * 4] = taps.reshape(Cout, KH, KW * 4)
+    return out
+
+
+def stem_view(canvas, cin_pad, kw):
+    """[N,Hp,Wp,4] canvas -> overlapping-window view [N,Hp,Wp-cin_pad/4+1,cin_pad] (in_sW = 4)."""
+    N, Hp, Wp, C = canvas.shape
+    assert C == 4 and canvas.is_contiguous()
+    return torch.as_strided(canvas, (N, Hp, Wp - cin_pad // 4 + 1, cin_pad), (Hp * Wp * 4, Wp * 4, 4, 1))
+
+
+class EastNet:
+    def __init__(self, state_dict, dtype=torch.float32, device="cuda"):
+        self.dtype, self.device = dtype, torch.device(device)
+        sd = {k: v for k, v in state_dict.items()}
+        P = {}
+
+        def conv_bn(name_conv, name_bn, bias_key=None):
+            w, b = fold_bn(sd[name_conv + ".weight"], sd.get(bias_key) if bias_key else None, name_bn, sd)
+            return w, b
+
+        bb = "backbone.extractor."
+        w, b = conv_bn(bb + "conv1", bb + "bn1")
+        P["stem"] = (pack_stem_weight(w, 32).to(dtype).to(self.device), b.to(self.device))
+        for lname, planes, blocks, stride in LAYERS:
+            for i in range(blocks):
+                p = f"{bb}{lname}.{i}."
+                for j in (1, 2, 3):
+                    w, b = conv_bn(p + f"conv{j}", p + f"bn{j}")
+                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+                if i == 0:
+                    w, b = conv_bn(p + "downsample.0", p + "downsample.1")
+                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+        for k in (1, 2, 3, 4):
+            p = f"decoder.block{k}."
+            w, b = conv_bn(p + "conv1x1.0", p + "conv1x1.1", p + "conv1x1.0.bias")
+            P[f"dec{k}.a"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+            w, b = conv_bn(p + "conv3x3.0", p + "conv3x3.1", p + "conv3x3.0.bias")
+            P[f"dec{k}.b"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+        w9 = torch.cat([sd["output_head.score_map.weight"].float().view(1, 32), sd["output_head.geo_map.weight"].float().view(8, 32)])
+        b9 = torch.cat([sd["output_head.score_map.bias"].float().view(1), sd["output_head.geo_map.bias"].float().view(8)])
+        self.w9, self.b9 = w9.contiguous().to(self.device), b9.contiguous().to(self.device)
+        self.P = P
+
+    # -------------------------------------------------------------------------------------
+    def _bottleneck(self, x, lname, i, stride, out=None):
+        P = self.P
+        w1, b1 = P[f"{lname}.{i}.conv1"]
+        w2, b2 = P[f"{lname}.{i}.conv2"]
+        w3, b3 = P[f"{lname}.{i}.conv3"]
+        o1 = ops.conv2d(x, w1, b1, relu=True)
+        o2 = ops.conv2d(o1, w2, b2, stride=(stride, stride), pad=(1, 1), relu=True)
+        if i == 0:
+            wd, bd = P[f"{lname}.{i}.down"]
+            idt = ops.conv2d(x, wd, bd, stride=(stride, stride))
+        else:
+            idt = x
+        return ops.conv2d(o2, w3, b3, relu=True, residual=idt, out=out)
+
+    def forward(self, pages_u8):
+        """pages_u8 [N,H,W,3] u8 on device, H and W multiples of 32 ->
+        (score [N,H/4,W/4] f32, geo [N,H/4,W/4,8] f32)."""
+        N, H, W, _ = pages_u8.shape
+        if H % 32 or W % 32:
+            raise ValueError("EAST network input must be a multiple of 32 in both dimensions (east.py:87-92 concats)")
+        dt, dev = self.dtype, self.device
+        canvas = ops.normalize_u8(pages_u8, 3, 3, H + 6, W + 6, 0, dt)
+        ws, bs = self.P["stem"]
+        x = ops.conv2d(stem_view(canvas, 32, 7), ws, bs, (2, 2), (0, 0), True, out_hw=(H // 2, W // 2))
+        del canvas
+        x = ops.maxpool2d(x, 3, 2, 1)
+        cat1 = torch.empty((N, H // 4, W // 4, 128 + 256), dtype=dt, device=dev)
+        cat2 = torch.empty((N, H // 8, W // 8, 256 + 512), dtype=dt, device=dev)
+        cat3 = torch.empty((N, H // 16, W // 16, 512 + 1024), dtype=dt, device=dev)
+        taps = {"layer1": cat1[..., 128:], "layer2": cat2[..., 256:], "layer3": cat3[..., 512:], "layer4": None}
+        for lname, planes, blocks, stride in LAYERS:
+            for i in range(blocks):
+                x = self._bottleneck(x, lname, i, stride if i == 0 else 1, out=taps[lname] if i == blocks - 1 else None)
+        P = self.P
+
+        def dec(k, t):
+            wa, ba = P[f"dec{k}.a"]
+            wb, bb_ = P[f"dec{k}.b"]
+            return ops.conv2d(ops.conv2d(t, wa, ba, relu=True), wb, bb_, pad=(1, 1), relu=True)
+
+        h4 = dec(1, x)
+        ops.upsample2x_into(h4, cat3)
+        h3 = dec(2, cat3)
+        ops.upsample2x_into(h3, cat2)
+        h2 = dec(3, cat2)
+        ops.upsample2x_into(h2, cat1)
+        h1 = dec(4, cat1)
+        return ops.east_head(h1, self.w9, self.b9)
+
+
+def east_conv_macs(H, W):
+    """Algorithmic multiply-accumulates of one page through the network."""
+    macs = (H // 2) * (W // 2) * 64 * 147
+    h, w, cin = H // 4, W // 4, 64
+    for lname, planes, blocks, stride in LAYERS:
+        for i in range(blocks):
+            s = stride if i == 0 else 1
+            macs += h * w * cin * planes
+            h2, w2 = h // s, w // s
+            macs += h2 * w2 * planes * planes * 9 + h2 * w2 * planes * planes * 4
+            if i == 0:
+                macs += h2 * w2 * cin * planes * 4
+            h, w, cin = h2, w2, planes * 4
+    for cin_, mid, cout, div in ((2048, 512, 512, 32), (1536, 256, 256, 16), (768, 128, 128, 8), (384, 64, 32, 4)):
+        px = (H // div) * (W // div)
+        macs += px * (cin_ * mid + mid * cout * 9)
+    macs += (H // 4) * (W // 4) * 32 * 9
+    return macs

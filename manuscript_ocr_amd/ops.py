@@ -1,0 +1,172 @@
+"""Thin tensor-level wrappers over the C ABI (device pointers + current HIP stream).
+
+PyTorch owns memory and streams only; all arithmetic happens in libmsocr.so.
+Activations are NHWC tensors [N, H, W, C] (possibly channel-slice views of a wider
+concat buffer: the kernels take explicit strides / leading dimensions).
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return nat.F32
+    if t.dtype == torch.bfloat16:
+        return nat.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise nat.NativeError("native ops need device tensors (no CPU fallback)")
+
+
+def _pixel_dense_ld(t):
+    """Leading dimension (elements per pixel) of an NHWC tensor/view whose pixels are dense."""
+    N, H, W, C = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != W * ld or (N > 1 and t.stride(0) != H * W * ld) or ld < C:
+        raise ValueError(f"tensor is not pixel-dense NHWC: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None):
+    """x [N,H,W,Cin] (any N/H/W strides, channel stride 1), w [Cout,KH,KW,Cin], bias f32 [Cout] or None."""
+    _need_cuda(x, w, bias, residual, out)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cw = w.shape
+    assert Cw == Cin and w.is_contiguous() and w.dtype == x.dtype and x.stride(3) == 1
+    sh, sw = stride
+    ph, pw = pad
+    Ho, Wo = out_hw if out_hw else ((H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    assert out.shape == (N, Ho, Wo, Cout) and out.dtype == x.dtype
+    d = nat.ConvDesc()
+    d.dtype = _dt(x)
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.in_sN, d.in_sH, d.in_sW = x.stride(0), x.stride(1), x.stride(2)
+    d.KH, d.KW, d.stride_h, d.stride_w, d.pad_h, d.pad_w = KH, KW, sh, sw, ph, pw
+    d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
+    d.out_ld = _pixel_dense_ld(out)
+    flags = nat.CONV_RELU if relu else 0
+    rp = None
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype
+        d.res_ld = _pixel_dense_ld(residual)
+        flags |= nat.CONV_RESIDUAL
+        rp = residual.data_ptr()
+    d.flags = flags
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Cout and bias.is_contiguous()
+    rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rp,
+                                out.data_ptr(), _stream())
+    nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
+    return out
+
+
+def normalize_u8(imgs_u8, pad_t, pad_l, Hp, Wp, mode, dtype):
+    """imgs [N,H,W,3] u8 (device) -> [N,Hp,Wp,4] normalised, zero canvas (mode 0 EAST, 1 TRBA)."""
+    _need_cuda(imgs_u8)
+    N, H, W, C = imgs_u8.shape
+    assert C == 3 and imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous()
+    out = torch.empty((N, Hp, Wp, 4), dtype=dtype, device=imgs_u8.device)
+    nat.check(nat.lib().msocr_normalize_u8(imgs_u8.data_ptr(), N, H, W, pad_t, pad_l, Hp, Wp, mode, _dt(out), out.data_ptr(), _stream()),
+              "normalize_u8")
+    return out
+
+
+def resize_linear_u8(src, dh, dw):
+    _need_cuda(src)
+    N, sh, sw, C = src.shape
+    assert C == 3 and src.dtype == torch.uint8 and src.is_contiguous()
+    dst = torch.empty((N, dh, dw, 3), dtype=torch.uint8, device=src.device)
+    nat.check(nat.lib().msocr_resize_linear_u8(src.data_ptr(), N, sh, sw, dst.data_ptr(), dh, dw, _stream()), "resize_linear_u8")
+    return dst
+
+
+def maxpool2d(x, k, s, p, out=None):
+    _need_cuda(x, out)
+    N, H, W, C = x.shape
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    nat.check(nat.lib().msocr_maxpool2d(x.data_ptr(), N, H, W, C, _pixel_dense_ld(x), k, s, p, _dt(x), out.data_ptr(), Ho, Wo,
+                                        _pixel_dense_ld(out), _stream()), "maxpool2d")
+    return out
+
+
+def upsample2x_into(x, out):
+    """Bilinear x2 of x [N,H,W,C] into out[..., :C] (out is [N,2H,2W,Ctot] or a channel-slice view)."""
+    _need_cuda(x, out)
+    N, H, W, C = x.shape
+    assert out.shape[0] == N and out.shape[1] == 2 * H and out.shape[2] == 2 * W and out.dtype == x.dtype
+    nat.check(nat.lib().msocr_upsample2x_bilinear(x.data_ptr(), N, H, W, C, _pixel_dense_ld(x), _dt(x), out.data_ptr(),
+                                                  _pixel_dense_ld(out), _stream()), "upsample2x")
+    return out
+
+
+def east_head(h1, w9, b9, score=None, geo=None):
+    _need_cuda(h1, w9, b9)
+    N, H, W, C = h1.shape
+    assert C == 32 and w9.shape == (9, 32) and w9.dtype == torch.float32
+    if score is None:
+        score = torch.empty((N, H, W), dtype=torch.float32, device=h1.device)
+    if geo is None:
+        geo = torch.empty((N, H, W, 8), dtype=torch.float32, device=h1.device)
+    nat.check(nat.lib().msocr_east_head(h1.data_ptr(), N * H * W, _pixel_dense_ld(h1), _dt(h1), w9.data_ptr(), b9.data_ptr(),
+                                        score.data_ptr(), geo.data_ptr(), _stream()), "east_head")
+    return score, geo
+
+
+def east_decode(score, geo, thresh, scale, quant, max_cand):
+    """score [N,H,W] f32, geo [N,H,W,8] f32 -> cand [N,max_cand,9] f32, counts [N] int32."""
+    _need_cuda(score, geo)
+    N, H, W = score.shape
+    assert score.dtype == torch.float32 and geo.shape == (N, H, W, 8) and score.is_contiguous() and geo.is_contiguous()
+    cand = torch.empty((N, max_cand, 9), dtype=torch.float32, device=score.device)
+    counts = torch.empty((N,), dtype=torch.int32, device=score.device)
+    nat.check(nat.lib().msocr_east_decode(score.data_ptr(), geo.data_ptr(), N, H, W, float(thresh), float(scale), int(quant),
+                                          cand.data_ptr(), counts.data_ptr(), max_cand, _stream()), "east_decode")
+    return cand, counts
+
+
+def east_lanms(cand, counts, iou_thr, workspace=None):
+    _need_cuda(cand, counts)
+    N, max_cand, _ = cand.shape
+    if workspace is None:
+        nbytes = nat.lib().msocr_lanms_workspace_bytes(N, max_cand)
+        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=cand.device)
+    boxes = torch.empty_like(cand)
+    nbox = torch.empty((N,), dtype=torch.int32, device=cand.device)
+    nat.check(nat.lib().msocr_east_lanms(cand.data_ptr(), counts.data_ptr(), N, max_cand, float(iou_thr), boxes.data_ptr(),
+                                         nbox.data_ptr(), workspace.data_ptr(), _stream()), "east_lanms")
+    return boxes, nbox
+
+
+def nchw_to_nhwc(x_f32, dtype, out=None):
+    _need_cuda(x_f32)
+    N, C, H, W = x_f32.shape
+    assert x_f32.dtype == torch.float32 and x_f32.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=dtype, device=x_f32.device)
+    nat.check(nat.lib().msocr_nchw_f32_to_nhwc(x_f32.data_ptr(), N, C, H, W, _dt(out), out.data_ptr(), _pixel_dense_ld(out), _stream()),
+              "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    nat.check(nat.lib().msocr_nhwc_to_nchw_f32(x.data_ptr(), N, C, H, W, _pixel_dense_ld(x), _dt(x), out.data_ptr(), _stream()),
+              "nhwc_to_nchw")
+    return out

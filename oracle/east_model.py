@@ -169,6 +169,8 @@ def synth_east_state_dict(seed=20260128):
             if ".bn3." in k:
                 v.mul_(0.35)
     # heads: keep score logits spread around 0 and geometry O(10 px)
-    sd["output_head.score_map.weight"].mul_(2.0)
+    w = sd["output_head.score_map.weight"]
+    w.sub_(w.mean())  # h1 is post-ReLU (positive): zero-mean weights centre the logit
+    sd["output_head.score_map.bias"].fill_(-1.5)  # ~20-25 % of pixels above the 0.6 threshold
     sd["output_head.geo_map.weight"].mul_(6.0)
     return sd

@@ -141,14 +141,17 @@ void orc_normalize_polygon(const double *ref, const double *poly, double *out) {
     }
 }
 
-/* stable argsort helpers (merge sort on index arrays) */
+/* stable argsort helpers (merge sort on index arrays); total order = ascending key, NaN last
+ * (np.argsort semantics), ties by original index */
+static int less_f32(float a, float b) { return a < b || (b != b && a == a); }
+static int less_f64(double a, double b) { return a < b || (b != b && a == a); }
 static void msort_f32(const float *key, int64_t *idx, int64_t *tmp, int64_t n) {
     if (n < 2) return;
     int64_t h = n / 2;
     msort_f32(key, idx, tmp, h);
     msort_f32(key, idx + h, tmp, n - h);
     int64_t i = 0, j = h, k = 0;
-    while (i < h && j < n) tmp[k++] = (key[idx[j]] < key[idx[i]]) ? idx[j++] : idx[i++];
+    while (i < h && j < n) tmp[k++] = less_f32(key[idx[j]], key[idx[i]]) ? idx[j++] : idx[i++];
     while (i < h) tmp[k++] = idx[i++];
     while (j < n) tmp[k++] = idx[j++];
     memcpy(idx, tmp, sizeof(int64_t) * n);
@@ -160,7 +163,7 @@ static void msort_f64_desc(const double *key, int64_t *idx, int64_t *tmp, int64_
     msort_f64_desc(key, idx + h, tmp, n - h);
     int64_t i = 0, j = h, k = 0;
     /* ascending in -score */
-    while (i < h && j < n) tmp[k++] = (-key[idx[j]] < -key[idx[i]]) ? idx[j++] : idx[i++];
+    while (i < h && j < n) tmp[k++] = less_f64(-key[idx[j]], -key[idx[i]]) ? idx[j++] : idx[i++];
     while (i < h) tmp[k++] = idx[i++];
     while (j < n) tmp[k++] = idx[j++];
     memcpy(idx, tmp, sizeof(int64_t) * n);

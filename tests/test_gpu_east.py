@@ -1,0 +1,66 @@
+"""EAST network on HIP vs the oracle's CPU fp32 restatement (same seeded synthetic weights)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import east_model as oem
+    sd = oem.synth_east_state_dict(seed=20260128)
+    net = oem.EASTNet()
+    net.load_state_dict(sd)
+    net.eval()
+    return sd, net
+
+
+def _page(seed, H, W):
+    from manuscript_ocr_amd import synth
+    return synth.synth_page(seed, H, W)[0]
+
+
+@pytest.mark.parametrize("hw", [(128, 160), (256, 192)])
+def test_east_forward_f32_matches_oracle(setup, hw):
+    """fp32 parity mode: tolerance 1e-4 absolute on the sigmoid score map, 1e-3 relative-to-max on
+    geometry; summation order differs from oneDNN, BN is folded."""
+    from manuscript_ocr_amd.detectors._east.net import EastNet
+    from oracle import imgproc
+    sd, ref_net = setup
+    H, W = hw
+    pages = np.stack([_page(11, H, W), _page(12, H, W)])
+    x = torch.from_numpy(np.concatenate([imgproc.east_preprocess(p, W, H) for p in pages]))
+    with torch.no_grad():
+        ref = ref_net(x)
+    net = EastNet(sd, torch.float32)
+    score, geo = net.forward(torch.from_numpy(pages).cuda())
+    torch.cuda.synchronize()
+    rs, rg = ref["score"][:, 0].numpy(), ref["geometry"].permute(0, 2, 3, 1).numpy()
+    assert score.shape == rs.shape and geo.shape == rg.shape
+    es = np.abs(score.cpu().numpy() - rs).max()
+    eg = np.abs(geo.cpu().numpy() - rg).max() / max(np.abs(rg).max(), 1.0)
+    assert rs.std() > 0.01, "degenerate score map: weights do not exercise the network"
+    assert es < 1e-4 and eg < 1e-3, (es, eg)
+    # identical candidate set at the default threshold
+    assert np.array_equal(score.cpu().numpy() > np.float32(0.6), rs > np.float32(0.6)) or es < 1e-5
+
+
+def test_east_forward_bf16_close(setup):
+    """bf16 throughput mode: stated tolerance 0.05 absolute on score, 5 % of max on geometry."""
+    from manuscript_ocr_amd.detectors._east.net import EastNet
+    from oracle import imgproc
+    sd, ref_net = setup
+    H, W = 128, 160
+    pages = np.stack([_page(13, H, W)])
+    x = torch.from_numpy(np.concatenate([imgproc.east_preprocess(p, W, H) for p in pages]))
+    with torch.no_grad():
+        ref = ref_net(x)
+    net = EastNet(sd, torch.bfloat16)
+    score, geo = net.forward(torch.from_numpy(pages).cuda())
+    rs, rg = ref["score"][:, 0].numpy(), ref["geometry"].permute(0, 2, 3, 1).numpy()
+    es = np.abs(score.cpu().numpy() - rs).max()
+    eg = np.abs(geo.cpu().numpy() - rg).max() / max(np.abs(rg).max(), 1.0)
+    assert es < 0.05 and eg < 0.05, (es, eg)

@@ -1,0 +1,227 @@
+"""GPU parity tests of the individual HIP ops, through the C ABI (libmsocr.so).
+
+Floating-point kernels are compared with a plain PyTorch fp32 CPU reference of the same
+op (tolerances stated per test); integer / index / fp64-geometry work (decode, LANMS) is
+compared bit-for-bit with the oracle and the committed golden vectors.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from manuscript_ocr_amd import ops as _ops
+    return _ops
+
+
+def _to_nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def _w_khwc(w, dtype):
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, relu, residual
+    (2, 17, 23, 64, 256, (1, 1), (1, 1), (0, 0), True, True),
+    (1, 20, 28, 64, 64, (3, 3), (1, 1), (1, 1), True, False),
+    (2, 19, 21, 128, 128, (3, 3), (2, 2), (1, 1), True, False),
+    (1, 16, 24, 256, 512, (1, 1), (2, 2), (0, 0), False, False),
+    (1, 24, 40, 64, 32, (3, 3), (1, 1), (1, 1), True, False),
+    (3, 4, 13, 512, 512, (2, 2), (2, 1), (0, 1), True, False),
+    (1, 9, 11, 2048, 512, (1, 1), (1, 1), (0, 0), True, False),
+    (1, 33, 47, 32, 64, (3, 3), (1, 1), (1, 1), False, False),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_vs_torch(ops, case, dtype, tol):
+    N, H, W, Cin, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) * (2.0 / (Cin * k[0] * k[1])) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    if dtype == torch.bfloat16:  # compare on the bf16-rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        if dtype == torch.bfloat16:
+            res = res.bfloat16().float()
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d(_to_nhwc(x, dtype), _w_khwc(w, dtype), b.cuda(), stride, pad, relu,
+                     _to_nhwc(res, dtype) if use_res else None)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * max(scale, 1.0), (err, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_concat_slices(ops, dtype):
+    """Input read from / output written into channel slices of wider concat buffers."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 1, 12, 20
+    x = torch.randn(N, 64, H, W, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, None, padding=1)
+    big_in = torch.zeros(N, H, W, 64 + 32, dtype=dtype, device="cuda")
+    big_in[..., 32:] = _to_nhwc(x, dtype)
+    big_out = torch.full((N, H, W, 128 + 64), 7.0, dtype=dtype, device="cuda")
+    ops.conv2d(big_in[..., 32:], _w_khwc(w, dtype), None, (1, 1), (1, 1), False, None, out=big_out[..., 64:])
+    torch.cuda.synchronize()
+    got = big_out[..., 64:].float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+    assert torch.all(big_out[..., :64].float() == 7.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_stem_7x7_packed(ops, dtype, tol):
+    """ResNet stem 7x7/2 p3 on C=3 via the padded-C4 canvas + packed [64][7][1][32] weights."""
+    from manuscript_ocr_amd.detectors._east.net import pack_stem_weight, stem_view
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 2, 64, 96
+    img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    x = ((img.float() / 255.0) - 0.5) / 0.5
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float()
+        xr = x.bfloat16().float()
+    else:
+        xr = x
+    ref = F.relu(F.conv2d(xr.permute(0, 3, 1, 2), w, b, stride=2, padding=3))
+    canvas = ops.normalize_u8(img.cuda(), 3, 3, H + 6, W + 6 + 2, 0, dtype)
+    out = ops.conv2d(stem_view(canvas, 32, 7), pack_stem_weight(w, 32).to(dtype).cuda(), b.cuda(), (2, 2), (0, 0), True,
+                     out_hw=(H // 2, W // 2))
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_upsample_head(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 18, 26, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = _to_nhwc(x, dtype)
+    mp = ops.maxpool2d(xd, 3, 2, 1).float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(mp, F.max_pool2d(x, 3, 2, 1))
+    mp2 = ops.maxpool2d(xd, 2, 2, 0).float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(mp2, F.max_pool2d(x, 2, 2))
+    cat = torch.zeros(2, 36, 52, 64 + 32, dtype=dtype, device="cuda")
+    ops.upsample2x_into(xd, cat)
+    up = cat[..., :64].float().cpu().permute(0, 3, 1, 2)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert (up - ref).abs().max().item() <= tol * ref.abs().max().item()
+    assert torch.all(cat[..., 64:] == 0)
+    h1 = torch.randn(2, 32, 10, 14, generator=g)
+    if dtype == torch.bfloat16:
+        h1 = h1.bfloat16().float()
+    w9, b9 = torch.randn(9, 32, generator=g) * 0.3, torch.randn(9, generator=g)
+    score, geo = ops.east_head(_to_nhwc(h1, dtype), w9.cuda(), b9.cuda())
+    o = F.conv2d(h1, w9.view(9, 32, 1, 1), b9)
+    np.testing.assert_allclose(score.cpu().numpy(), torch.sigmoid(o[:, 0]).numpy(), atol=2e-6)
+    np.testing.assert_allclose(geo.cpu().numpy(), o[:, 1:].permute(0, 2, 3, 1).numpy(), atol=1e-5)
+
+
+def test_normalize_and_resize_vs_oracle(ops):
+    from oracle import imgproc
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(2, 37, 53, 3), dtype=np.uint8)
+    can = ops.normalize_u8(torch.from_numpy(img).cuda(), 3, 3, 37 + 6, 53 + 8, 0, torch.float32).cpu().numpy()
+    ref = imgproc.east_preprocess(img[0], 53, 37)[0].transpose(1, 2, 0)
+    assert np.array_equal(can[0, 3:40, 3:56, :3], ref)
+    assert np.all(can[:, :3] == 0) and np.all(can[:, :, :3] == 0) and np.all(can[..., 3] == 0) and np.all(can[:, :, 56:] == 0)
+    can1 = ops.normalize_u8(torch.from_numpy(img).cuda(), 1, 1, 39, 60, 1, torch.float32).cpu().numpy()
+    ref1 = (img[1].astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)
+    assert np.array_equal(can1[1, 1:38, 1:54, :3], ref1)
+    for (dh, dw) in ((64, 96), (20, 31), (37, 53), (74, 106)):
+        got = ops.resize_linear_u8(torch.from_numpy(img).cuda(), dh, dw).cpu().numpy()
+        for n in range(2):
+            assert np.array_equal(got[n], imgproc.resize_linear_u8(img[n], dw, dh)), (dh, dw)
+    big = rng.integers(0, 256, size=(1, 40, 60, 3), dtype=np.uint8)
+    got = ops.resize_linear_u8(torch.from_numpy(big).cuda(), 20, 30).cpu().numpy()
+    assert np.array_equal(got[0], imgproc.resize_linear_u8(big[0], 30, 20))
+
+
+def _nan_eq(a, b):
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def test_decode_golden_bit_exact(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "east_post.npz"))
+    score = torch.from_numpy(g["score"]).cuda()[None].contiguous()
+    geo = torch.from_numpy(g["geo"]).cuda()[None].contiguous()
+    for q, thr, key in ((1, 0.6, "decoded_q1"), (2, 0.6, "decoded_q2"), (4, 0.6, "decoded_q4"), (2, 0.9, "decoded_thr09_q2")):
+        cand, cnt = ops.east_decode(score, geo, thr, 4.0, q, 16384)
+        n = int(cnt.cpu()[0])
+        exp = g[key]
+        assert n == len(exp), (key, n, len(exp))
+        assert np.array_equal(cand[0, :n].cpu().numpy().view(np.uint32), exp.view(np.uint32)), key
+    cand, cnt = ops.east_decode(torch.zeros_like(score), geo, 0.6, 4.0, 2, 64)
+    assert int(cnt.cpu()[0]) == 0
+    cand, cnt = ops.east_decode(score, geo, 0.6, 4.0, 2, 100)  # overflow flagged, first rows intact
+    c = int(cnt.cpu()[0])
+    assert c < 0 and (c & 0x7FFFFFFF) == 100
+    assert np.array_equal(cand[0].cpu().numpy().view(np.uint32), g["decoded_q2"][:100].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["page_small", "page_mid", "rot_1", "rot_50", "rot_600", "rot_rev_40"])
+def test_lanms_golden_bit_exact(ops, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "lanms.npz"))
+    inp, exp = g[f"{name}_in"], g[f"{name}_out"]
+    mc = 2048
+    cand = torch.zeros(2, mc, 9, dtype=torch.float32, device="cuda")
+    cand[0, :len(inp)] = torch.from_numpy(inp).cuda()
+    cand[1, :len(inp)] = torch.from_numpy(inp).cuda()
+    counts = torch.tensor([len(inp), 0], dtype=torch.int32, device="cuda")
+    boxes, nbox = ops.east_lanms(cand, counts, 0.2)
+    nb = nbox.cpu().numpy()
+    assert nb[0] == len(exp) and nb[1] == 0
+    got = boxes[0, :nb[0]].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_decode_lanms_pipeline_vs_oracle(ops):
+    """Full-size injected maps (384x512, ~10k candidates): HIP decode+LANMS == oracle, bit for bit."""
+    from manuscript_ocr_amd import synth
+    from oracle import east_post as P
+    from oracle import lanms as L
+    N, H, W = 2, 1536, 2048
+    scores, geos = [], []
+    for n in range(N):
+        rects = synth.synth_layout(300 + n, H, W)
+        s, g_ = synth.synth_maps(rects, (H, W), (H // 4, W // 4), 300 + n)
+        scores.append(s), geos.append(g_)
+    score = torch.from_numpy(np.stack(scores)).cuda()
+    geo = torch.from_numpy(np.stack(geos)).cuda()
+    cand, cnt = ops.east_decode(score, geo, 0.6, 4.0, 2, 32768)
+    boxes, nbox = ops.east_lanms(cand, cnt, 0.2)
+    cnt, nbox = cnt.cpu().numpy(), nbox.cpu().numpy()
+    for n in range(N):
+        dec = P.decode_quads_from_maps(scores[n], geos[n], 0.6, 4.0, 2)
+        assert cnt[n] == len(dec) and len(dec) > 5000
+        assert np.array_equal(cand[n, :cnt[n]].cpu().numpy().view(np.uint32), dec.view(np.uint32))
+        exp = L.locality_aware_nms(dec, 0.2)
+        assert nbox[n] == len(exp)
+        assert np.array_equal(boxes[n, :nbox[n]].cpu().numpy().view(np.uint32), exp.view(np.uint32))
