@@ -54,12 +54,12 @@ typedef struct msocr_conv_desc {
 int msocr_conv2d(const msocr_conv_desc* d, const void* in, const void* weight, const float* bias,
                  const void* residual, void* out, void* stream);
 
-/* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->4 inside a zero canvas
- * out[N][Hp][Wp][4], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
+/* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->cpad (4 or 8) inside a zero canvas
+ * out[N][Hp][Wp][cpad], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
  *   mode 0: EAST ToTensor+Normalize, detectors/_east/infer.py:127-132,305  -> (x/255 - .5)/.5
  *   mode 1: TRBA A.Normalize(.5,.5,max 255), recognizers/_trba/data/transforms.py:185-193 -> (x-127.5)*f32(1/127.5) */
-int msocr_normalize_u8(const uint8_t* src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, int mode,
-                       int dtype, void* out, void* stream);
+int msocr_normalize_u8(const uint8_t* src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, int cpad,
+                       int mode, int dtype, void* out, void* stream);
 
 /* cv2.resize(img,(dw,dh)) INTER_LINEAR for u8 HxWx3 (OpenCV 11-bit fixed point), batched.
  * Replaces detectors/_east/infer.py:304 (restated from OpenCV, parity unpinned). */
@@ -110,10 +110,6 @@ int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int dtype, flo
 int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out,
                            void* stream);
 
-/* Dense f32 GEMM-with-bias on VALU for the small linears: out[M][N] = x[M][K] W^T[K][N] + b. w_t = [K][N]. */
-int msocr_linear_f32(const float* x, const float* w_t, const float* bias, int M, int K, int N, float* out,
-                     void* stream);
-
 typedef struct msocr_attn_weights {
   const float* h2h_wt;   /* [H][H]   h2h.weight^T */
   const float* h2h_b;    /* [H] */
@@ -126,19 +122,27 @@ typedef struct msocr_attn_weights {
   const float* gen_b;    /* [V] */
 } msocr_attn_weights;
 
-/* Attention decode (model/model.py:34-46 cell, :227-259 greedy, :92-225 beam), one workgroup per batch row,
- * whole loop in one launch.  batch_H, proj_H: [B][T][H] f32 (proj_H = i2h(batch_H), hoisted).
- * greedy: steps = max_len+1; logits_out [B][steps][V], ids_out [B][steps] int32.
- * beam:   steps = max_len; outputs are the best beam's path (temperature-scaled logits), plus
- *         fin_step_out [B] = first step index after which every beam of the row is finished (or steps).
- * The reference's batch-level early break (model.py:215,254) is applied by the host from these. */
+/* Attention decode (model/model.py:34-46 cell, :227-259 greedy, :92-225 beam): one workgroup per batch row,
+ * the whole step loop in ONE launch (rows are independent).  batch_H, proj_H: [B][T][H] f32 with
+ * proj_H = i2h(batch_H) hoisted out of the loop (the reference recomputes it every step); H == 256, T <= 48,
+ * V <= 256, steps <= 64.
+ * greedy: steps = max_len+1; logits_out [B][steps][V] f32, ids_out [B][steps] i32 for ALL steps.
+ * beam  : steps = max_len; per step the kernel stores every beam's temperature-scaled logits, back-pointers,
+ *         tokens and the arg-max beam into `workspace`, and fin_step_out[b] = number of steps after which every
+ *         beam of row b is finished (or steps).  lp_dev[steps] = f32 length-penalty factors
+ *         ((5+t+1)^alpha / 6^alpha, computed by the host exactly as model.py:160) or NULL when alpha <= 0.
+ * The reference stops the loop for the whole batch chunk (model.py:215,254); the host derives each row's run length
+ * t_run from ids/fin_step and msocr_attn_beam_finalize walks the back-pointers from (t_run-1, best beam at t_run-1):
+ * logits_out [B][steps][V] (rows t < t_run valid), ids_out [B][steps] (-1 beyond t_run). */
 int msocr_attn_greedy(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
                       int V, int steps, int sos_id, int eos_id, int blank_id, float* logits_out, int32_t* ids_out,
                       void* stream);
-int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
-                    int V, int steps, int beam, float alpha, float temperature, int sos_id, int eos_id, int blank_id,
-                    float* logits_out, int32_t* ids_out, int32_t* fin_step_out, void* workspace, void* stream);
 int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, int V);
+int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
+                    int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
+                    int blank_id, int32_t* fin_step_out, void* workspace, void* stream);
+int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
+                             float* logits_out, int32_t* ids_out, void* stream);
 
 /* u8 crops -> normalised TRBA batch (ResizeAndPadA+Normalize, recognizers/_trba/data/transforms.py:62-120,185-193)
  * from boxes of a device-resident page: next-round item; round 1 preprocesses crops on the host. */

@@ -7,6 +7,9 @@ C ABI sees raw pointers and sizes.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: libmsocr.so's NEEDED libamdhip64.so.7 then binds to the HIP
+#                              runtime PyTorch already loaded (one runtime per process; two runtimes = launch failures)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsocr.so")
 
@@ -33,7 +36,7 @@ class AttnWeights(ctypes.Structure):
 
 _SIGS = {
     "msocr_conv2d": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "msocr_upsample2x_bilinear": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
@@ -44,12 +47,12 @@ _SIGS = {
     "msocr_se_residual": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_mean_over_h": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_bilstm_recurrent": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "msocr_linear_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_attn_greedy": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_vp, c_vp, c_vp]),
-    "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32,
-                                c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,
+                                c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "msocr_attn_beam_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "msocr_attn_beam_finalize": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "msocr_nchw_f32_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "msocr_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "msocr_version": (ctypes.c_char_p, []),

@@ -16,6 +16,10 @@
 
 #include "msocr.h"
 
+// Clear any stale (sticky) HIP error left by earlier runtime calls of the host process before a launch,
+// so that the status read back after it belongs to this launch.
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -295,7 +299,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   }
   const long nblk = (long)p.tilesM * p.tilesN;
   if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, s, p);
+  MSOCR_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 

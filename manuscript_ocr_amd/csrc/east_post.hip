@@ -11,6 +11,10 @@
 
 #include "msocr.h"
 
+// Clear any stale (sticky) HIP error left by earlier runtime calls of the host process before a launch,
+// so that the status read back after it belongs to this launch.
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH)
 
 // ------------------------------------------------------------------------------------------ decode
@@ -80,7 +84,7 @@ extern "C" int msocr_east_decode(const float* score, const float* geo, int N, in
                                  float* cand_out, int32_t* count_out, int max_cand, void* stream) {
   if (!score || !geo || !cand_out || !count_out || N <= 0 || H <= 0 || W <= 0 || quant <= 0 || max_cand <= 0) return MSOCR_E_ARG;
   if (H % quant || W % quant) return MSOCR_E_ARG;  // the reference would index out of range (utils.py:349-356,369)
-  hipLaunchKernelGGL(east_decode_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, score, geo, H, W, thresh, (double)scale, quant,
+  MSOCR_LAUNCH(east_decode_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, score, geo, H, W, thresh, (double)scale, quant,
                      cand_out, count_out, max_cand);
   return LAUNCH_OK();
 }
@@ -311,7 +315,7 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
   if (!cand || !counts || !boxes_out || !nbox_out || !workspace || N <= 0 || max_cand <= 0) return MSOCR_E_ARG;
   if ((uintptr_t)workspace & 7) return MSOCR_E_ARG;
   const long stride = (lanms_ws_per_page(max_cand) + 63) / 64 * 64;
-  hipLaunchKernelGGL(east_lanms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
+  MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
                      (char*)workspace, stride);
   return LAUNCH_OK();
 }

@@ -6,6 +6,10 @@
 
 #include "msocr.h"
 
+// Clear any stale (sticky) HIP error left by earlier runtime calls of the host process before a launch,
+// so that the status read back after it belongs to this launch.
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -35,7 +39,7 @@ template <> __device__ __forceinline__ void st<uint16_t>(uint16_t* p, float v) {
 // (image placed at (pad_t, pad_l)); the zero border IS the convolution padding of the stem.
 //   mode 0 (EAST, infer.py:127-132,305): ToTensor then Normalize -> (x/255 - .5)/.5, two f32 roundings
 //   mode 1 (TRBA, transforms.py:185-193): A.Normalize(.5,.5,255) -> (x - 127.5) * f32(1/127.5)
-template <typename T>
+template <typename T, int CP>
 __global__ void normalize_u8_kernel(const uint8_t* __restrict__ src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                                     int mode, T* __restrict__ dst) {
   const long total = (long)N * Hp * Wp;
@@ -61,26 +65,37 @@ __global__ void normalize_u8_kernel(const uint8_t* __restrict__ src, int N, int 
     }
     if (sizeof(T) == 4) {
       f32x4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+      *reinterpret_cast<f32x4*>(dst + i * CP) = o;
+      if (CP == 8) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(dst + i * CP + 4) = z;
+      }
     } else {
       u32x2 o = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
-      *reinterpret_cast<u32x2*>(dst + i * 4) = o;
+      *reinterpret_cast<u32x2*>(dst + i * CP) = o;
+      if (CP == 8) {
+        u32x2 z = {0u, 0u};
+        *reinterpret_cast<u32x2*>(dst + i * CP + 4) = z;
+      }
     }
   }
 }
 
-extern "C" int msocr_normalize_u8(const uint8_t* src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, int mode, int dtype,
-                                  void* out, void* stream) {
+extern "C" int msocr_normalize_u8(const uint8_t* src, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, int cpad, int mode,
+                                  int dtype, void* out, void* stream) {
   if (!src || !out || N <= 0 || H <= 0 || W <= 0 || pad_t < 0 || pad_l < 0 || Hp < H + pad_t || Wp < W + pad_l) return MSOCR_E_ARG;
-  if (mode != 0 && mode != 1) return MSOCR_E_ARG;
+  if ((mode != 0 && mode != 1) || (cpad != 4 && cpad != 8)) return MSOCR_E_ARG;
   const long total = (long)N * Hp * Wp;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(normalize_u8_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode,
-                       (float*)out);
+  const dim3 g(grid_for(total, 256)), b(256);
+  if (dtype == MSOCR_F32 && cpad == 4)
+    MSOCR_LAUNCH((normalize_u8_kernel<float, 4>), g, b, 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode, (float*)out);
+  else if (dtype == MSOCR_F32)
+    MSOCR_LAUNCH((normalize_u8_kernel<float, 8>), g, b, 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode, (float*)out);
+  else if (dtype == MSOCR_BF16 && cpad == 4)
+    MSOCR_LAUNCH((normalize_u8_kernel<uint16_t, 4>), g, b, 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode, (uint16_t*)out);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(normalize_u8_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode,
-                       (uint16_t*)out);
+    MSOCR_LAUNCH((normalize_u8_kernel<uint16_t, 8>), g, b, 0, s, src, N, H, W, pad_t, pad_l, Hp, Wp, mode, (uint16_t*)out);
   else
     return MSOCR_E_ARG;
   return LAUNCH_OK();
@@ -140,7 +155,7 @@ extern "C" int msocr_resize_linear_u8(const uint8_t* src, int N, int sh, int sw,
   const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
   const int area2x = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
   const long total = (long)N * dh * dw;
-  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, N, sh, sw, dst,
+  MSOCR_LAUNCH(resize_linear_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, N, sh, sw, dst,
                      dh, dw, scale_x, scale_y, area2x);
   return LAUNCH_OK();
 }
@@ -183,10 +198,10 @@ extern "C" int msocr_maxpool2d(const void* in, int N, int H, int W, int C, int64
   const long total = (long)N * Ho * Wo * (C / 4);
   hipStream_t st_ = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st_, (const float*)in, N, H, W, C, (long)in_ld, k, s, p,
+    MSOCR_LAUNCH(maxpool_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st_, (const float*)in, N, H, W, C, (long)in_ld, k, s, p,
                        (float*)out, Ho, Wo, (long)out_ld);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st_, (const uint16_t*)in, N, H, W, C, (long)in_ld, k,
+    MSOCR_LAUNCH(maxpool_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st_, (const uint16_t*)in, N, H, W, C, (long)in_ld, k,
                        s, p, (uint16_t*)out, Ho, Wo, (long)out_ld);
   else
     return MSOCR_E_ARG;
@@ -232,10 +247,10 @@ extern "C" int msocr_upsample2x_bilinear(const void* in, int N, int H, int W, in
   const long total = (long)N * 4 * H * W * (C / 4);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N, H, W, C, (long)in_ld,
+    MSOCR_LAUNCH(upsample2x_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N, H, W, C, (long)in_ld,
                        (float*)out, (long)out_ld);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const uint16_t*)in, N, H, W, C,
+    MSOCR_LAUNCH(upsample2x_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const uint16_t*)in, N, H, W, C,
                        (long)in_ld, (uint16_t*)out, (long)out_ld);
   else
     return MSOCR_E_ARG;
@@ -287,10 +302,10 @@ extern "C" int msocr_east_head(const void* h1, int64_t npix, int64_t in_ld, int 
   if (!h1 || !w9 || !b9 || !score_out || !geo_out || npix <= 0 || in_ld < 32) return MSOCR_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(east_head_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const float*)h1, (long)npix, (long)in_ld, w9, b9,
+    MSOCR_LAUNCH(east_head_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const float*)h1, (long)npix, (long)in_ld, w9, b9,
                        score_out, geo_out);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(east_head_kernel<uint16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const uint16_t*)h1, (long)npix, (long)in_ld, w9,
+    MSOCR_LAUNCH(east_head_kernel<uint16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const uint16_t*)h1, (long)npix, (long)in_ld, w9,
                        b9, score_out, geo_out);
   else
     return MSOCR_E_ARG;
@@ -328,9 +343,9 @@ extern "C" int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int 
   const long total = (long)N * C * H * W;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, in, N, C, H, W, (float*)out, (long)out_ld);
+    MSOCR_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, in, N, C, H, W, (float*)out, (long)out_ld);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, in, N, C, H, W, (uint16_t*)out, (long)out_ld);
+    MSOCR_LAUNCH(nchw_to_nhwc_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, in, N, C, H, W, (uint16_t*)out, (long)out_ld);
   else
     return MSOCR_E_ARG;
   return LAUNCH_OK();
@@ -340,9 +355,9 @@ extern "C" int msocr_nhwc_to_nchw_f32(const void* in, int N, int C, int H, int W
   const long total = (long)N * C * H * W;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N, C, H, W, (long)in_ld, out);
+    MSOCR_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N, C, H, W, (long)in_ld, out);
   else if (dtype == MSOCR_BF16)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const uint16_t*)in, N, C, H, W, (long)in_ld, out);
+    MSOCR_LAUNCH(nhwc_to_nchw_kernel<uint16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const uint16_t*)in, N, C, H, W, (long)in_ld, out);
   else
     return MSOCR_E_ARG;
   return LAUNCH_OK();

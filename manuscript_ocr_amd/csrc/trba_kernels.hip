@@ -1,10 +1,634 @@
-// placeholder until the TRBA kernels land (replaced in the next commit)
+// trba_kernels.hip — the non-convolutional part of the TRBA recogniser on gfx950:
+// squeeze-excite tail, mean over H, BiLSTM recurrence and the attention decoder
+// (greedy and beam).  These stages are bandwidth/latency bound: they run
+// on the VALU in exact f32 with coalesced weight streams (weights pre-transposed so lane j
+// reads column j), LDS-resident per-row state and wave-level reductions; no MFMA.
+// The sequential loops (T encoder steps, <= 26 decoder steps) live INSIDE one launch:
+// rows are independent, so one workgroup owns a row (or a few) for the whole loop and no
+// inter-workgroup hand-off exists.
+//
+//   msocr_se_residual       <- recognizers/_trba/model/seresnet31.py:5-20, 61-66
+//   msocr_mean_over_h       <- recognizers/_trba/model/model.py:388-390
+//   msocr_bilstm_recurrent  <- model.py:9-21 (nn.LSTM, gate order i,f,g,o)
+//   msocr_attn_greedy       <- model.py:34-46 + 227-259
+//   msocr_attn_beam(+_finalize) <- model.py:34-46 + 92-225
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
 #include "msocr.h"
-extern "C" int msocr_se_residual(const void*, const void*, int, int, int, int, const float*, const float*, float*, void*, void*) { return MSOCR_E_ARG; }
-extern "C" int msocr_mean_over_h(const void*, int, int, int, int, int, float*, void*) { return MSOCR_E_ARG; }
-extern "C" int msocr_bilstm_recurrent(const float*, const float*, int, int, int, float*, void*) { return MSOCR_E_ARG; }
-extern "C" int msocr_linear_f32(const float*, const float*, const float*, int, int, int, float*, void*) { return MSOCR_E_ARG; }
-extern "C" int msocr_attn_greedy(const float*, const float*, const msocr_attn_weights*, int, int, int, int, int, int, int, int, float*, int32_t*, void*) { return MSOCR_E_ARG; }
-extern "C" int msocr_attn_beam(const float*, const float*, const msocr_attn_weights*, int, int, int, int, int, int, float, float, int, int, int, float*, int32_t*, int32_t*, void*, void*) { return MSOCR_E_ARG; }
-extern "C" int64_t msocr_attn_beam_workspace_bytes(int, int, int, int) { return 0; }
+
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<uint16_t>(const uint16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<uint16_t>(uint16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// --------------------------------------------------------------------------------------------- SE tail
+// One workgroup per sample: mean over HW (coalesced over channels), two tiny FCs, then
+// out = relu(x * gate + identity).  x is re-read from L2 for the last phase.
+template <typename T>
+__global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ x, const T* __restrict__ idt, int HW, int C,
+                                                           const float* __restrict__ w1, const float* __restrict__ w2,
+                                                           float* __restrict__ gate_ws, T* __restrict__ out) {
+  extern __shared__ float sm[];  // mean[C] | hid[C/16] | gate[C]
+  float* mean = sm;
+  float* hid = sm + C;
+  float* gate = hid + C / 16;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const T* xs = x + (long)n * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += ldf<T>(xs + (long)p * C + c);
+    mean[c] = s * inv;
+  }
+  __syncthreads();
+  const int Cr = C / 16;
+  {  // hid = relu(W1 mean): one wave per output, lanes over C
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int j = wv; j < Cr; j += 4) {
+      float a = 0.f;
+      for (int c = lane; c < C; c += 64) a = fmaf(w1[(long)j * C + c], mean[c], a);
+      a = wave_sum(a);
+      if (lane == 0) hid[j] = fmaxf(a, 0.f);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int j = 0; j < Cr; ++j) a = fmaf(w2[(long)c * Cr + j], hid[j], a);
+    const float g = sigmoidf_(a);
+    gate[c] = g;
+    gate_ws[(long)n * C + c] = g;
+  }
+  __syncthreads();
+  const T* is = idt + (long)n * HW * C;
+  T* os = out + (long)n * HW * C;
+  const long tot = (long)HW * C;
+  for (long i = tid; i < tot; i += 256) {
+    const int c = (int)(i % C);
+    const float v = ldf<T>(xs + i) * gate[c] + ldf<T>(is + i);
+    stf<T>(os + i, fmaxf(v, 0.f));
+  }
+}
+
+extern "C" int msocr_se_residual(const void* x, const void* identity, int N, int HW, int C, int dtype, const float* w1, const float* w2,
+                                 float* gate_ws, void* out, void* stream) {
+  if (!x || !identity || !w1 || !w2 || !gate_ws || !out || N <= 0 || HW <= 0 || C <= 0 || C % 16) return MSOCR_E_ARG;
+  const size_t lds = (size_t)(2 * C + C / 16) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MSOCR_F32)
+    MSOCR_LAUNCH(se_residual_kernel<float>, dim3(N), dim3(256), lds, s, (const float*)x, (const float*)identity, HW, C, w1, w2, gate_ws,
+                 (float*)out);
+  else if (dtype == MSOCR_BF16)
+    MSOCR_LAUNCH(se_residual_kernel<uint16_t>, dim3(N), dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)identity, HW, C, w1, w2,
+                 gate_ws, (uint16_t*)out);
+  else
+    return MSOCR_E_ARG;
+  return LAUNCH_OK();
+}
+
+// --------------------------------------------------------------------------------------------- mean over H
+template <typename T>
+__global__ void mean_over_h_kernel(const T* __restrict__ in, int N, int H, int W, int C, float* __restrict__ out) {
+  const long total = (long)N * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long t = i / C;
+    const int w = (int)(t % W);
+    const int n = (int)(t / W);
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += ldf<T>(in + (((long)n * H + h) * W + w) * C + c);
+    out[i] = s / (float)H;
+  }
+}
+extern "C" int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int dtype, float* out, void* stream) {
+  if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MSOCR_E_ARG;
+  const long total = (long)N * W * C;
+  long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MSOCR_F32)
+    MSOCR_LAUNCH(mean_over_h_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)in, N, H, W, C, out);
+  else if (dtype == MSOCR_BF16)
+    MSOCR_LAUNCH(mean_over_h_kernel<uint16_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint16_t*)in, N, H, W, C, out);
+  else
+    return MSOCR_E_ARG;
+  return LAUNCH_OK();
+}
+
+// --------------------------------------------------------------------------------------------- BiLSTM recurrence
+// grid (ceil(B/RB), 2 directions), 256 threads = hidden units (H == 256).  Thread j owns unit j's
+// four gates for RB batch rows; h_{t-1} of the RB rows sits in LDS as [k][r] so one
+// ds_read_b128 pair broadcasts the 8 row values of column k; W_hh^T rows stream from L2,
+// coalesced over j.  xproj already holds x W_ih^T + b_ih + b_hh.
+#define LSTM_RB 8
+__global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t, int B, int T,
+                                                      float* __restrict__ hcat) {
+  constexpr int H = 256, G = 4 * H, RB = LSTM_RB;
+  __shared__ __attribute__((aligned(16))) float hs[2][H][RB];
+  const int j = threadIdx.x, d = blockIdx.y;
+  const int b0 = blockIdx.x * RB;
+  const float* wt = whh_t + (long)d * H * G;
+  float c[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    c[r] = 0.f;
+    hs[0][j][r] = 0.f;
+  }
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+    const int cur = s & 1;
+    float acc[4][RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int b = b0 + r < B ? b0 + r : B - 1;
+      const float* xp = xproj + (((long)b * T + t) * 2 + d) * G;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][r] = xp[g * H + j];
+    }
+#pragma unroll 4
+    for (int k = 0; k < H; ++k) {
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[cur][k][0]);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[cur][k][4]);
+      const float hv[RB] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float w = wt[(long)k * G + g * H + j];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[g][r] = fmaf(w, hv[r], acc[g][r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      const float h = og * tanhf(c[r]);
+      hs[cur ^ 1][j][r] = h;
+      if (b0 + r < B) hcat[((long)(b0 + r) * T + t) * (2 * H) + d * H + j] = h;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out, void* stream) {
+  if (!xproj || !w_hh_t || !hcat_out || B <= 0 || T <= 0 || H != 256) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(bilstm_kernel, dim3((B + LSTM_RB - 1) / LSTM_RB, 2), dim3(256), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  return LAUNCH_OK();
+}
+
+// --------------------------------------------------------------------------------------------- attention decoder
+// One workgroup (256 threads, H == 256) per batch row; K = 1 (greedy) or beam states.
+// LDS: batch_H[T][H], proj_H[T][H] of this row, h / ctx as [k][r], ph[r][j], alpha[r][t], logits[r][v].
+#define ATT_H 256
+#define ATT_KMAX 8
+
+struct AttnArgs {
+  const float* batch_H;
+  const float* proj_H;
+  msocr_attn_weights w;
+  int B, T, V, steps, K;
+  int sos_id, eos_id, blank_id;
+  float temperature;
+  const float* lp;      // [steps] f32 length-penalty factors (beam, alpha > 0) or nullptr
+  float* logits_out;    // greedy: [B][steps][V]; beam: workspace [B][steps][K][V]
+  int32_t* ids_out;     // greedy: [B][steps]
+  int32_t* back;        // beam: [B][steps][K]
+  int32_t* tokv;        // beam: [B][steps][K]
+  int32_t* best_at;     // beam: [B][steps]
+  int32_t* fin_step;    // beam: [B]
+};
+
+template <int K>
+__device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, const float* sH, const float* sP, float (*sh)[ATT_KMAX],
+                                                    float (*sctx)[ATT_KMAX], float (*sph)[ATT_H], float (*salpha)[64],
+                                                    float (*slog)[256], float (&c)[K], const int* tok, int T, int V) {
+  constexpr int H = ATT_H;
+  const int j = tid;
+  // (a) ph[r][j] = h2h(h)[j]
+  {
+    float acc[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) acc[r] = a.w.h2h_b[j];
+    for (int k = 0; k < H; ++k) {
+      const float w = a.w.h2h_wt[(long)k * H + j];
+#pragma unroll
+      for (int r = 0; r < K; ++r) acc[r] = fmaf(w, sh[k][r], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) sph[r][j] = acc[r];
+  }
+  __syncthreads();
+  // (b) e[r][t] = score . tanh(proj_H[t] + ph[r]) : one wave per (r,t) pair, lanes over j
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int p = wv; p < K * T; p += 4) {
+      const int r = p / T, t = p - r * T;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) {
+        const int jj = lane + 64 * q;
+        s = fmaf(a.w.score_w[jj], tanhf(sP[t * H + jj] + sph[r][jj]), s);
+      }
+      s = wave_sum(s);
+      if (lane == 0) salpha[r][t] = s;
+    }
+  }
+  __syncthreads();
+  // (c) softmax over t (T <= 64): thread r
+  if (tid < K) {
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t) m = fmaxf(m, salpha[tid][t]);
+    float sum = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float e = expf(salpha[tid][t] - m);
+      salpha[tid][t] = e;
+      sum += e;
+    }
+    for (int t = 0; t < T; ++t) salpha[tid][t] = salpha[tid][t] / sum;
+  }
+  __syncthreads();
+  // (d) ctx[r][j] = sum_t alpha[r][t] * batch_H[t][j]
+  {
+    float acc[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) acc[r] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float hv = sH[t * H + j];
+#pragma unroll
+      for (int r = 0; r < K; ++r) acc[r] = fmaf(salpha[r][t], hv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) sctx[j][r] = acc[r];
+  }
+  __syncthreads();
+  // (e) LSTMCell gates: W_ih[:, :H] ctx + W_ih[:, H+tok] + W_hh h + (b_ih + b_hh); thread j owns unit j
+  float g4[4][K];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < K; ++r) g4[g][r] = a.w.b_gates[g * H + j] + a.w.wih_tok[(long)tok[r] * 4 * H + g * H + j];
+  for (int k = 0; k < H; ++k) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float w = a.w.wih_ctx_t[(long)k * 4 * H + g * H + j];
+#pragma unroll
+      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w, sctx[k][r], g4[g][r]);
+    }
+  }
+  for (int k = 0; k < H; ++k) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float w = a.w.whh_t[(long)k * 4 * H + g * H + j];
+#pragma unroll
+      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w, sh[k][r], g4[g][r]);
+    }
+  }
+  __syncthreads();  // everyone finished reading the old h
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const float ig = sigmoidf_(g4[0][r]), fg = sigmoidf_(g4[1][r]), gg = tanhf(g4[2][r]), og = sigmoidf_(g4[3][r]);
+    c[r] = fg * c[r] + ig * gg;
+    sh[j][r] = og * tanhf(c[r]);
+  }
+  __syncthreads();
+  // (f) generator logits[r][v]
+  if (tid < V) {
+    float acc[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) acc[r] = a.w.gen_b[tid];
+    for (int k = 0; k < H; ++k) {
+      const float w = a.w.gen_wt[(long)k * V + tid];
+#pragma unroll
+      for (int r = 0; r < K; ++r) acc[r] = fmaf(w, sh[k][r], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) slog[r][tid] = (tid == a.blank_id) ? -1e4f : acc[r];
+  }
+  __syncthreads();
+}
+
+// block-wide arg-max over (value, index) pairs with "larger value, then smaller index" order
+__device__ __forceinline__ void block_argmax(float v, int idx, float* s_val, int* s_idx, int tid, float& out_v, int& out_i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(idx, o);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = idx; }
+  __syncthreads();
+  out_v = s_val[0];
+  out_i = s_idx[0];
+  for (int w = 1; w < 4; ++w)
+    if (s_val[w] > out_v || (s_val[w] == out_v && s_idx[w] < out_i)) { out_v = s_val[w]; out_i = s_idx[w]; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
+  constexpr int H = ATT_H, K = 1;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // batch_H[T][H] | proj_H[T][H]
+  __shared__ __attribute__((aligned(16))) float sh[H][ATT_KMAX], sctx[H][ATT_KMAX];
+  __shared__ float sph[K][H], salpha[K][64], slog[K][256];
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  const int b = blockIdx.x, tid = threadIdx.x, T = a.T, V = a.V;
+  float* sH = dyn;
+  float* sP = dyn + T * H;
+  for (int i = tid; i < T * H; i += 256) {
+    sH[i] = a.batch_H[(long)b * T * H + i];
+    sP[i] = a.proj_H[(long)b * T * H + i];
+  }
+  float c[K] = {0.f};
+  sh[tid][0] = 0.f;
+  int tok[K] = {a.sos_id};
+  __syncthreads();
+  for (int s = 0; s < a.steps; ++s) {
+    attention_cell_step<K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    if (tid < V) {
+      v = slog[0][tid];
+      idx = tid;
+      a.logits_out[((long)b * a.steps + s) * V + tid] = v;
+    }
+    float bv;
+    int bi;
+    block_argmax(v, idx, s_val, s_idx, tid, bv, bi);
+    tok[0] = bi;
+    if (tid == 0) a.ids_out[(long)b * a.steps + s] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_beam_kernel(AttnArgs a) {
+  constexpr int H = ATT_H, K = ATT_KMAX;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  __shared__ __attribute__((aligned(16))) float sh[H][ATT_KMAX], sctx[H][ATT_KMAX];
+  __shared__ float sph[K][H], salpha[K][64], slog[K][256];
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_score[K], s_lse[K], s_top[K];
+  __shared__ int s_tok[K], s_done[K], s_src[K], s_nxt[K];
+  const int b = blockIdx.x, tid = threadIdx.x, T = a.T, V = a.V, KB = a.K;
+  float* sH = dyn;
+  float* sP = dyn + T * H;
+  for (int i = tid; i < T * H; i += 256) {
+    sH[i] = a.batch_H[(long)b * T * H + i];
+    sP[i] = a.proj_H[(long)b * T * H + i];
+  }
+  float c[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    c[r] = 0.f;
+    sh[tid][r] = 0.f;
+  }
+  if (tid < K) {
+    s_score[tid] = tid == 0 ? 0.f : -INFINITY;
+    s_tok[tid] = a.sos_id;
+    s_done[tid] = 0;
+  }
+  __syncthreads();
+  int fin = a.steps;
+  const float temp = fmaxf(a.temperature, 1e-6f);
+  for (int s = 0; s < a.steps; ++s) {
+    int tok[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) tok[r] = s_tok[r];
+    attention_cell_step<K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
+    // temperature (true f32 division, model.py:135-137), keep the scaled logits for the trace
+    if (tid < V) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        float v = slog[r][tid];
+        if (a.temperature != 1.0f) v = v / temp;
+        slog[r][tid] = v;
+        if (r < KB) a.logits_out[(((long)b * a.steps + s) * KB + r) * V + tid] = v;
+      }
+    }
+    __syncthreads();
+    // log_softmax per beam row: wave w handles rows w, w+4
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      for (int r = wv; r < KB; r += 4) {
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, slog[r][v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int v = lane; v < V; v += 64) sum += expf(slog[r][v] - m);
+        sum = wave_sum(sum);
+        if (lane == 0) s_lse[r] = m + logf(sum);
+      }
+    }
+    __syncthreads();
+    // candidates: cand[r][v] = (score[r] + logp[r][v]) / lp ; finished beams: only EOS with logp 0
+    const float lp = a.lp ? a.lp[s] : 1.0f;
+    float cv[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      cv[r] = -INFINITY;
+      if (tid < V && r < KB) {
+        float logp = slog[r][tid] - s_lse[r];  // log_softmax = x - (max + log(sum exp(x - max)))
+        if (s_done[r]) logp = (tid == a.eos_id) ? 0.f : -INFINITY;
+        float tot = s_score[r] + logp;
+        if (a.lp) tot = tot / lp;
+        cv[r] = tot;
+      }
+    }
+    // top-K by K rounds of block arg-max over the K*V candidates (flat index = r*V + v)
+    for (int kk = 0; kk < KB; ++kk) {
+      float bvv = -INFINITY;
+      int bii = 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const int fi = r * V + tid;
+        if (tid < V && r < KB && (cv[r] > bvv || (cv[r] == bvv && fi < bii))) { bvv = cv[r]; bii = fi; }
+      }
+      if (!(tid < V)) bii = 0x7fffffff;
+      float wv_;
+      int wi_;
+      block_argmax(bvv, bii, s_val, s_idx, tid, wv_, wi_);
+      if (wi_ == 0x7fffffff) wi_ = 0;  // all candidates -inf/NaN: degenerate, pick index 0 like a fallback
+      if (tid == 0) {
+        s_top[kk] = wv_;
+        s_src[kk] = wi_ / V;
+        s_nxt[kk] = wi_ % V;
+      }
+      // remove the winner: NaN never wins a comparison again
+      if (tid < V) {
+        const int wr = wi_ / V, wc = wi_ - wr * V;
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+          if (r == wr && tid == wc) cv[r] = __int_as_float(0x7fc00000);
+      }
+      __syncthreads();
+    }
+    // reorder beam state by src
+    float cn[K], hn[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int src = r < KB ? s_src[r] : r;
+      float cc = 0.f, hh = 0.f;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        cc = (q == src) ? c[q] : cc;
+        hh = (q == src) ? sh[tid][q] : hh;
+      }
+      cn[r] = cc;
+      hn[r] = hh;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      c[r] = cn[r];
+      sh[tid][r] = hn[r];
+    }
+    int alldone = 1;
+    int nd[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      nd[r] = r < KB ? (s_done[s_src[r]] | (s_nxt[r] == a.eos_id)) : 1;
+      alldone &= nd[r];
+    }
+    __syncthreads();
+    if (tid < KB) {
+      const long o = ((long)b * a.steps + s) * KB + tid;
+      a.back[o] = s_src[tid];
+      a.tokv[o] = s_nxt[tid];
+      s_score[tid] = a.lp ? s_top[tid] * lp : s_top[tid];  // f32 round trip of the reference (model.py:188-192)
+      s_tok[tid] = s_nxt[tid];
+      s_done[tid] = nd[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // best beam if the loop stopped after this step: argmax of the un-normalised sums, first maximum
+      int best = 0;
+      float bs = s_score[0];
+      for (int r = 1; r < KB; ++r)
+        if (s_score[r] > bs) { bs = s_score[r]; best = r; }
+      a.best_at[(long)b * a.steps + s] = best;
+    }
+    if (alldone && fin == a.steps) fin = s + 1;
+    __syncthreads();
+  }
+  if (tid == 0) a.fin_step[b] = fin;
+}
+
+// finalize: walk the back-pointers from (t_run-1, best_at[t_run-1]) and gather the path's logits
+__global__ void attn_beam_finalize_kernel(const float* __restrict__ ws_logits, const int32_t* __restrict__ back,
+                                          const int32_t* __restrict__ tokv, const int32_t* __restrict__ best_at,
+                                          const int32_t* __restrict__ trun, int V, int steps, int K, float* __restrict__ logits_out,
+                                          int32_t* __restrict__ ids_out) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int path[64];
+  const int tr = trun[b];
+  if (tid == 0) {
+    int cur = best_at[(long)b * steps + tr - 1];
+    for (int t = tr - 1; t >= 0; --t) {
+      const long o = ((long)b * steps + t) * K + cur;
+      ids_out[(long)b * steps + t] = tokv[o];
+      path[t] = back[o];  // row of the PARENT beam whose logits produced this token (model.py:198-201)
+      cur = back[o];
+    }
+    for (int t = tr; t < steps; ++t) ids_out[(long)b * steps + t] = -1;
+  }
+  __syncthreads();
+  for (int t = 0; t < tr; ++t)
+    for (int v = tid; v < V; v += blockDim.x)
+      logits_out[((long)b * steps + t) * V + v] = ws_logits[(((long)b * steps + t) * K + path[t]) * V + v];
+}
+
+static int check_attn(const float* bh, const float* ph, const msocr_attn_weights* w, int B, int T, int H, int V, int steps) {
+  if (!bh || !ph || !w || B <= 0 || T <= 0 || T > 48 || H != ATT_H || V <= 0 || V > 256 || steps <= 0 || steps > 64) return MSOCR_E_ARG;
+  if (!w->h2h_wt || !w->h2h_b || !w->score_w || !w->wih_ctx_t || !w->wih_tok || !w->whh_t || !w->b_gates || !w->gen_wt || !w->gen_b)
+    return MSOCR_E_ARG;
+  return MSOCR_OK;
+}
+
+extern "C" int msocr_attn_greedy(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H, int V,
+                                 int steps, int sos_id, int eos_id, int blank_id, float* logits_out, int32_t* ids_out, void* stream) {
+  if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !logits_out || !ids_out) return MSOCR_E_ARG;
+  if (sos_id < 0 || sos_id >= V) return MSOCR_E_ARG;
+  AttnArgs a{};
+  a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w;
+  a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = 1;
+  a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = 1.0f;
+  a.logits_out = logits_out; a.ids_out = ids_out;
+  const size_t lds = (size_t)2 * T * ATT_H * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr = true;
+  }
+  MSOCR_LAUNCH(attn_greedy_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+  return LAUNCH_OK();
+}
+
+// workspace: logits [B][steps][K][V] f32 | back [B][steps][K] i32 | tokv [B][steps][K] i32 | best_at [B][steps] i32
+static inline int64_t beam_ws_logits(int B, int steps, int K, int V) { return (int64_t)B * steps * K * V * 4; }
+extern "C" int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, int V) {
+  if (B <= 0 || steps <= 0 || beam <= 0 || V <= 0) return 0;
+  return beam_ws_logits(B, steps, beam, V) + (int64_t)B * steps * beam * 8 + (int64_t)B * steps * 4 + 256;
+}
+
+extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H, int V,
+                               int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
+                               int32_t* fin_step_out, void* workspace, void* stream) {
+  if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !fin_step_out || !workspace) return MSOCR_E_ARG;
+  if (beam < 1 || beam > ATT_KMAX || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
+  AttnArgs a{};
+  a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w;
+  a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = beam;
+  a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = temperature; a.lp = lp_dev;
+  char* p = (char*)workspace;
+  a.logits_out = (float*)p; p += beam_ws_logits(B, steps, beam, V);
+  a.back = (int32_t*)p; p += (int64_t)B * steps * beam * 4;
+  a.tokv = (int32_t*)p; p += (int64_t)B * steps * beam * 4;
+  a.best_at = (int32_t*)p;
+  a.fin_step = fin_step_out;
+  const size_t lds = (size_t)2 * T * ATT_H * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr = true;
+  }
+  MSOCR_LAUNCH(attn_beam_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+  return LAUNCH_OK();
+}
+
+extern "C" int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
+                                        float* logits_out, int32_t* ids_out, void* stream) {
+  if (!workspace || !trun_dev || !logits_out || !ids_out || B <= 0 || V <= 0 || steps <= 0 || steps > 64 || beam < 1 || beam > ATT_KMAX)
+    return MSOCR_E_ARG;
+  const char* p = (const char*)workspace;
+  const float* wl = (const float*)p; p += beam_ws_logits(B, steps, beam, V);
+  const int32_t* back = (const int32_t*)p; p += (int64_t)B * steps * beam * 4;
+  const int32_t* tokv = (const int32_t*)p; p += (int64_t)B * steps * beam * 4;
+  const int32_t* best_at = (const int32_t*)p;
+  MSOCR_LAUNCH(attn_beam_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, wl, back, tokv, best_at, trun_dev, V, steps, beam,
+               logits_out, ids_out);
+  return LAUNCH_OK();
+}

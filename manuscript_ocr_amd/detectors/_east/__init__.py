@@ -1,0 +1,3 @@
+from .infer import EAST
+
+__all__ = ["EAST"]

@@ -1,0 +1,180 @@
+"""EAST detector plugin — drop-in for the reference class
+(/root/reference/src/manuscript/detectors/_east/infer.py:27-402, inference half).
+
+Same constructor knobs, same `predict` signature, return dict and exceptions.  The
+network, quad decode and locality-aware NMS run on the MI355X through libmsocr.so
+(manuscript_ocr_amd/csrc); there is no CPU execution path — constructing the detector
+without a HIP device raises.
+
+Extensions (keyword-only, all optional):
+  precision   "fp32" (parity mode, exact-f32 MFMA) | "bf16" (throughput mode, f32 accumulate)
+  state_dict  in-memory weights in the reference key layout (offline: no download is possible)
+  target_size may also be a (W, H) tuple: native non-square network input (multiples of 32)
+  predict_batch(pages)  list/array of same-sized RGB pages -> list of result dicts, one launch
+                        sequence for the whole batch (the reference is strictly one page per call)
+"""
+import time
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from ... import ops
+from .._types import Block, Page, Word
+from . import post
+from .net import EastNet
+from .utils import read_image, sort_boxes_reading_order_with_resolutions, visualize_page
+
+_DEFAULT_WEIGHT_LOCATIONS = (
+    Path("weights") / "east_quad_23_05.pth",
+    Path.home() / ".manuscript" / "east" / "east_quad_23_05.pth",
+)
+
+
+class EAST:
+    def __init__(
+        self,
+        weights_path: Optional[Union[str, Path]] = None,
+        device: Optional[str] = None,
+        target_size: Union[int, Tuple[int, int]] = 1280,
+        expand_ratio_w: float = 0.9,
+        expand_ratio_h: float = 0.9,
+        score_thresh: float = 0.6,
+        iou_threshold: float = 0.2,
+        score_geo_scale: float = 0.25,
+        quantization: int = 2,
+        axis_aligned_output: bool = True,
+        remove_area_anomalies: bool = True,
+        anomaly_sigma_threshold: float = 5.0,
+        anomaly_min_box_count: int = 30,
+        *,
+        precision: str = "fp32",
+        state_dict: Optional[Dict[str, torch.Tensor]] = None,
+        max_candidates: int = 65536,
+    ):
+        self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
+        if not str(self.device).startswith("cuda") or not torch.cuda.is_available():
+            raise RuntimeError(
+                f"manuscript_ocr_amd.EAST runs only on a HIP device (MI355X); device={self.device!r}, "
+                f"torch.cuda.is_available()={torch.cuda.is_available()}. There is no CPU fallback."
+            )
+        if state_dict is None:
+            if weights_path is None:
+                # the reference downloads east_quad_23_05.pth with gdown (infer.py:96-107); no network here
+                found = next((p for p in _DEFAULT_WEIGHT_LOCATIONS if p.exists()), None)
+                if found is None:
+                    raise FileNotFoundError(
+                        "EAST weights not found: pass weights_path=... (or state_dict=...), or place east_quad_23_05.pth under "
+                        "./weights/ or ~/.manuscript/east/ (automatic download is unavailable offline)."
+                    )
+                weights_path = found
+            if not Path(weights_path).exists():
+                raise FileNotFoundError(f"EAST weights not found: {weights_path}")
+            state_dict = torch.load(str(weights_path), map_location="cpu", weights_only=True)
+        self.precision = precision
+        dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[precision]
+        self.model = EastNet(state_dict, dtype=dtype, device=self.device)
+
+        self.target_size = target_size
+        self.score_geo_scale = score_geo_scale
+        self.expand_ratio_w = expand_ratio_w
+        self.expand_ratio_h = expand_ratio_h
+        self.score_thresh = score_thresh
+        self.iou_threshold = iou_threshold
+        self.quantization = quantization
+        self.axis_aligned_output = axis_aligned_output
+        self.remove_area_anomalies = remove_area_anomalies
+        self.anomaly_sigma_threshold = anomaly_sigma_threshold
+        self.anomaly_min_box_count = anomaly_min_box_count
+        self.max_candidates = max_candidates
+        if abs(1.0 / score_geo_scale - 4.0) > 1e-9:
+            raise ValueError("the network emits maps at 1/4 resolution (east.py:126-127): score_geo_scale must be 0.25")
+
+    # ------------------------------------------------------------------------------------- helpers
+    def _target_wh(self):
+        t = self.target_size
+        return (int(t), int(t)) if np.isscalar(t) else (int(t[0]), int(t[1]))
+
+    def detect_device(self, pages_dev: torch.Tensor, maps_override=None):
+        """pages_dev [N,h,w,3] u8 on the device (any size) -> device tensors
+        (score, geo, boxes [N,max_cand,9], nbox [N]).  Resize, network, decode and LANMS, all HIP."""
+        tw, th = self._target_wh()
+        if pages_dev.shape[1] != th or pages_dev.shape[2] != tw:
+            pages_dev = ops.resize_linear_u8(pages_dev, th, tw)
+        score, geo = self.model.forward(pages_dev)
+        if maps_override is not None:  # benchmark / parity harness: injected maps
+            score.copy_(maps_override[0], non_blocking=True)
+            geo.copy_(maps_override[1], non_blocking=True)
+        cand, counts = ops.east_decode(score, geo, self.score_thresh, 1.0 / self.score_geo_scale, self.quantization,
+                                       self.max_candidates)
+        boxes, nbox = ops.east_lanms(cand, counts, self.iou_threshold)
+        return score, geo, boxes, nbox, counts
+
+    def _host_tail(self, quads: np.ndarray, orig_hw) -> np.ndarray:
+        """infer.py:340-356 on the (M,9) f32 NMS output."""
+        q = post.expand_boxes(quads, self.expand_ratio_w, self.expand_ratio_h)
+        q = post.scale_boxes(q, orig_hw, self._target_wh())
+        q = post.remove_contained(q)
+        q = post.remove_area_anomalies(q, self.remove_area_anomalies, self.anomaly_sigma_threshold, self.anomaly_min_box_count)
+        return post.to_axis_aligned(q) if self.axis_aligned_output else q
+
+    @staticmethod
+    def _words(quads: np.ndarray) -> List[Word]:
+        return [Word(polygon=q[:8].reshape(4, 2).tolist(), detection_confidence=float(q[8])) for q in quads]
+
+    @staticmethod
+    def _sort_words(words: List[Word]) -> List[Word]:
+        def aabb(w):
+            poly = np.array(w.polygon, dtype=np.int32)
+            (x0, y0), (x1, y1) = np.min(poly, axis=0), np.max(poly, axis=0)
+            return (x0, y0, x1, y1)
+
+        boxes = [aabb(w) for w in words]
+        out = []
+        for bx in sort_boxes_reading_order_with_resolutions(boxes):
+            for w, wb in zip(words, boxes):
+                if wb == bx:
+                    out.append(w)
+                    break
+        return out
+
+    # ------------------------------------------------------------------------------------- API
+    def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
+                      sort_reading_order=False, _maps_override=None) -> List[Dict[str, Any]]:
+        imgs = [read_image(im) for im in images]
+        if len({im.shape for im in imgs}) != 1:
+            raise ValueError("predict_batch needs equally sized pages")
+        t0 = time.time()
+        pages = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
+        score, geo, boxes, nbox, counts = self.detect_device(pages, _maps_override)
+        nbox_h = nbox.cpu().numpy()
+        counts_h = counts.cpu().numpy()
+        if np.any(counts_h < 0):
+            raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
+        boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
+        if profile:
+            print(f"  Model inference + decode + NMS (device): {time.time() - t0:.3f}s")
+            print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
+        results = []
+        for n, img in enumerate(imgs):
+            quads = self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
+            words = self._words(quads)
+            if sort_reading_order and words:
+                words = self._sort_words(words)
+            page = Page(blocks=[Block(words=words)])
+            results.append({
+                "page": page,
+                "vis_image": visualize_page(img, page, show_order=False) if vis else None,
+                "score_map": score[n].cpu().numpy() if return_maps else None,
+                "geo_map": geo[n].permute(2, 0, 1).contiguous().cpu().numpy() if return_maps else None,
+            })
+        return results
+
+    def predict(self, img_or_path: Union[str, Path, np.ndarray], vis: bool = False, profile: bool = False,
+                return_maps: bool = False, sort_reading_order: bool = False) -> Dict[str, Any]:
+        """Same contract as the reference EAST.predict (infer.py:235-402): keys
+        {"page","vis_image","score_map","geo_map"}; FileNotFoundError / TypeError on bad input."""
+        img = read_image(img_or_path)
+        return self.predict_batch([img], vis=vis, profile=profile, return_maps=return_maps,
+                                  sort_reading_order=sort_reading_order)[0]

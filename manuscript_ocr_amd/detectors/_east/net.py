@@ -36,22 +36,22 @@ def to_khwc(w, dtype, device):
     return w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device)
 
 
-def pack_stem_weight(w, cin_pad):
-    """OIHW stem weight (C=3) -> [Cout][KH][1][cin_pad] with element kw*4+c = w[co,c,kh,kw], zeros elsewhere."""
+def pack_stem_weight(w, cin_pad, cpad=4):
+    """OIHW stem weight (C=3) -> [Cout][KH][1][cin_pad] with element kw*cpad+c = w[co,c,kh,kw], zeros elsewhere."""
     Cout, C, KH, KW = w.shape
-    assert C <= 4 and KW * 4 <= cin_pad
-    taps = torch.zeros(Cout, KH, KW, 4, dtype=torch.float32)
+    assert C <= cpad and KW * cpad <= cin_pad
+    taps = torch.zeros(Cout, KH, KW, cpad, dtype=torch.float32)
     taps[..., :C] = w.float().permute(0, 2, 3, 1)
     out = torch.zeros(Cout, KH, 1, cin_pad, dtype=torch.float32)
-    out[:, :, 0, : KW * 4] = taps.reshape(Cout, KH, KW * 4)
+    out[:, :, 0, : KW * cpad] = taps.reshape(Cout, KH, KW * cpad)
     return out
 
 
-def stem_view(canvas, cin_pad, kw):
-    """[N,Hp,Wp,4] canvas -> overlapping-window view [N,Hp,Wp-cin_pad/4+1,cin_pad] (in_sW = 4)."""
+def stem_view(canvas, cin_pad, kw=None):
+    """[N,Hp,Wp,cpad] canvas -> overlapping-window view [N,Hp,Wp-cin_pad/cpad+1,cin_pad] (in_sW = cpad)."""
     N, Hp, Wp, C = canvas.shape
-    assert C == 4 and canvas.is_contiguous()
-    return torch.as_strided(canvas, (N, Hp, Wp - cin_pad // 4 + 1, cin_pad), (Hp * Wp * 4, Wp * 4, 4, 1))
+    assert C in (4, 8) and canvas.is_contiguous()
+    return torch.as_strided(canvas, (N, Hp, Wp - cin_pad // C + 1, cin_pad), (Hp * Wp * C, Wp * C, C, 1))
 
 
 class EastNet:
@@ -111,7 +111,7 @@ class EastNet:
         dt, dev = self.dtype, self.device
         canvas = ops.normalize_u8(pages_u8, 3, 3, H + 6, W + 6, 0, dt)
         ws, bs = self.P["stem"]
-        x = ops.conv2d(stem_view(canvas, 32, 7), ws, bs, (2, 2), (0, 0), True, out_hw=(H // 2, W // 2))
+        x = ops.conv2d(stem_view(canvas, 32, 7), ws, bs, (2, 2), (0, 0), True, out_hw=(H // 2, W // 2), alg_k=147)
         del canvas
         x = ops.maxpool2d(x, 3, 2, 1)
         cat1 = torch.empty((N, H // 4, W // 4, 128 + 256), dtype=dt, device=dev)

@@ -11,6 +11,11 @@ import torch
 from . import _native as nat
 
 
+# When set to a list, conv2d appends (start_event, end_event, algorithmic_flops, shape_tag) per launch;
+# bench.py uses it for the live HIP-event roofline of the dominant kernel.
+PROFILE = None
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return nat.F32
@@ -38,8 +43,9 @@ def _pixel_dense_ld(t):
     return ld
 
 
-def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None):
-    """x [N,H,W,Cin] (any N/H/W strides, channel stride 1), w [Cout,KH,KW,Cin], bias f32 [Cout] or None."""
+def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None, alg_k=None):
+    """x [N,H,W,Cin] (any N/H/W strides, channel stride 1), w [Cout,KH,KW,Cin], bias f32 [Cout] or None.
+    alg_k: algorithmic reduction length when the packed K is padded (stem), for FLOP accounting only."""
     _need_cuda(x, w, bias, residual, out)
     N, H, W, Cin = x.shape
     Cout, KH, KW, Cw = w.shape
@@ -67,19 +73,27 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     d.flags = flags
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout and bias.is_contiguous()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rp,
                                 out.data_ptr(), _stream())
     nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin), (N * Ho * Wo, Cout, KH * KW * Cin)))
     return out
 
 
-def normalize_u8(imgs_u8, pad_t, pad_l, Hp, Wp, mode, dtype):
-    """imgs [N,H,W,3] u8 (device) -> [N,Hp,Wp,4] normalised, zero canvas (mode 0 EAST, 1 TRBA)."""
+def normalize_u8(imgs_u8, pad_t, pad_l, Hp, Wp, mode, dtype, cpad=4):
+    """imgs [N,H,W,3] u8 (device) -> [N,Hp,Wp,cpad] normalised, zero canvas (mode 0 EAST, 1 TRBA)."""
     _need_cuda(imgs_u8)
     N, H, W, C = imgs_u8.shape
     assert C == 3 and imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous()
-    out = torch.empty((N, Hp, Wp, 4), dtype=dtype, device=imgs_u8.device)
-    nat.check(nat.lib().msocr_normalize_u8(imgs_u8.data_ptr(), N, H, W, pad_t, pad_l, Hp, Wp, mode, _dt(out), out.data_ptr(), _stream()),
+    out = torch.empty((N, Hp, Wp, cpad), dtype=dtype, device=imgs_u8.device)
+    nat.check(nat.lib().msocr_normalize_u8(imgs_u8.data_ptr(), N, H, W, pad_t, pad_l, Hp, Wp, cpad, mode, _dt(out), out.data_ptr(),
+                                           _stream()),
               "normalize_u8")
     return out
 
@@ -169,4 +183,38 @@ def nhwc_to_nchw_f32(x):
     out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
     nat.check(nat.lib().msocr_nhwc_to_nchw_f32(x.data_ptr(), N, C, H, W, _pixel_dense_ld(x), _dt(x), out.data_ptr(), _stream()),
               "nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- TRBA
+def se_residual(x, identity, w1, w2, out=None):
+    """relu(x * sigmoid(W2 relu(W1 mean_hw(x))) + identity); x, identity [N,H,W,C] contiguous."""
+    _need_cuda(x, identity, w1, w2)
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and identity.is_contiguous() and identity.shape == x.shape and identity.dtype == x.dtype
+    assert w1.shape == (C // 16, C) and w2.shape == (C, C // 16) and w1.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    gate = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    nat.check(nat.lib().msocr_se_residual(x.data_ptr(), identity.data_ptr(), N, H * W, C, _dt(x), w1.data_ptr(), w2.data_ptr(),
+                                          gate.data_ptr(), out.data_ptr(), _stream()), "se_residual")
+    return out
+
+
+def mean_over_h(x):
+    """[N,H,W,C] (dtype) -> [N,W,C] f32."""
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((N, W, C), dtype=torch.float32, device=x.device)
+    nat.check(nat.lib().msocr_mean_over_h(x.data_ptr(), N, H, W, C, _dt(x), out.data_ptr(), _stream()), "mean_over_h")
+    return out
+
+
+def bilstm_recurrent(xproj, whh_t, B, T, H):
+    """xproj [B*T, 2*4H] f32 (= [B][T][2][4H]), whh_t [2,H,4H] f32 -> hcat [B,T,2H] f32."""
+    _need_cuda(xproj, whh_t)
+    assert xproj.is_contiguous() and xproj.numel() == B * T * 8 * H and whh_t.shape == (2, H, 4 * H) and whh_t.is_contiguous()
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=xproj.device)
+    nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
     return out

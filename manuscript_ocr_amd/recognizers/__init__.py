@@ -1,0 +1,3 @@
+from ._trba import TRBA
+
+__all__ = ["TRBA"]

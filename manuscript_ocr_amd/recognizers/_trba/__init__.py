@@ -1,0 +1,192 @@
+"""TRBA recogniser plugin — drop-in for the reference class
+(/root/reference/src/manuscript/recognizers/_trba/__init__.py:23-434, inference half).
+
+Same constructor (model_path / charset_path / config_path / device / weights_path alias), same
+`predict` signature, outputs and exceptions.  SE-ResNet31, the BiLSTM encoder and the attention
+decoder (greedy and beam) run on the MI355X through libmsocr.so; there is no CPU execution path.
+
+Extensions (keyword-only): precision="fp32"|"bf16" for the CNN (recurrent/attention stages are
+always exact f32), state_dict=... / config=... for in-memory weights (nothing can be downloaded
+offline), device_batch=256 rows per launch sequence.  Confidences reproduce the reference's
+dependence on `batch_size` chunks (its decode loop stops per chunk, model.py:215,254).
+"""
+import json
+import os
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .net import TrbaNet
+from .transforms import decode_tokens, load_charset, resize_and_pad
+
+
+class TRBA:
+    _DEFAULT_PRESET_NAME = "exp_1_baseline"
+    _DEFAULT_STORAGE_ROOT = Path.home() / ".manuscript" / "trba"
+    _DEFAULT_WEIGHTS_FILENAME = "weights.pth"
+    _DEFAULT_CONFIG_FILENAME = "config.json"
+
+    def __init__(self, model_path: Optional[str] = None, charset_path: Optional[str] = None, config_path: Optional[str] = None,
+                 device: str = "auto", **kwargs: Any):
+        weights_path = kwargs.pop("weights_path", None)
+        precision = kwargs.pop("precision", "fp32")
+        state_dict = kwargs.pop("state_dict", None)
+        config = kwargs.pop("config", None)
+        self.device_batch = int(kwargs.pop("device_batch", 256))
+        if kwargs:
+            raise TypeError(f"Unexpected keyword argument(s): {', '.join(kwargs.keys())}")
+        if weights_path is not None and model_path is not None:
+            if os.path.abspath(os.fspath(weights_path)) != os.path.abspath(os.fspath(model_path)):
+                raise ValueError("Provide either model_path or weights_path, but not both with different values.")
+
+        if state_dict is None:
+            self.model_path, resolved_config = self._resolve_paths(weights_path if weights_path is not None else model_path, config_path)
+        else:
+            self.model_path, resolved_config = None, (os.fspath(config_path) if config_path is not None else None)
+            if resolved_config is not None and not os.path.exists(resolved_config):
+                raise FileNotFoundError(f"Config file not found: {resolved_config}")
+
+        if charset_path is None:
+            charset_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "charset.txt")
+        self.charset_path = os.fspath(charset_path)
+        self.config_path = resolved_config
+        if not os.path.exists(self.charset_path):
+            raise FileNotFoundError(f"Charset file not found: {self.charset_path}")
+        if config is None:
+            if self.config_path is not None:
+                with open(self.config_path, "r", encoding="utf-8") as f:
+                    config = json.load(f)
+            else:
+                config = {}
+        self.max_length = config.get("max_len", 25)
+        self.hidden_size = config.get("hidden_size", 256)
+        self.img_h = config.get("img_h", 64)
+        self.img_w = config.get("img_w", 256)
+
+        if device == "auto":
+            self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        else:
+            self.device = torch.device(device)
+        self.itos, self.stoi = load_charset(self.charset_path)
+        self.pad_id = self.stoi["<PAD>"]
+        self.sos_id = self.stoi["<SOS>"]
+        self.eos_id = self.stoi["<EOS>"]
+        self.blank_id = self.stoi.get("<BLANK>", None)
+
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError(
+                f"manuscript_ocr_amd.TRBA runs only on a HIP device (MI355X); device={self.device}, "
+                f"torch.cuda.is_available()={torch.cuda.is_available()}. There is no CPU fallback."
+            )
+        if state_dict is None:
+            obj = torch.load(self.model_path, map_location="cpu", weights_only=True)
+            state_dict = obj["model_state"] if isinstance(obj, dict) and "model_state" in obj else obj  # training/utils.py:54-59
+        self.precision = precision
+        self.model = TrbaNet(state_dict, len(self.itos), self.hidden_size,
+                             {"fp32": torch.float32, "bf16": torch.bfloat16}[precision], self.device)
+
+    # ------------------------------------------------------------------------------------- paths
+    def _resolve_paths(self, model_path, config_path) -> Tuple[str, Optional[str]]:
+        if model_path is None:
+            target = self._DEFAULT_STORAGE_ROOT.expanduser() / self._DEFAULT_PRESET_NAME
+            for cand in (Path("weights") / "trba" / self._DEFAULT_WEIGHTS_FILENAME, target / self._DEFAULT_WEIGHTS_FILENAME):
+                if cand.exists():
+                    model_path = os.fspath(cand)
+                    break
+            else:  # the reference downloads trba_exp_1_64.pth/.json with gdown (__init__.py:207-243); no network here
+                raise FileNotFoundError(
+                    "TRBA weights not found: pass model_path=... (or state_dict=...), or place weights.pth (+config.json) under "
+                    "./weights/trba/ or ~/.manuscript/trba/exp_1_baseline/ (automatic download is unavailable offline)."
+                )
+        resolved = os.fspath(model_path)
+        if not os.path.exists(resolved):
+            raise FileNotFoundError(f"Model checkpoint not found: {resolved}")
+        if config_path is not None:
+            cfg = os.fspath(config_path)
+            if not os.path.exists(cfg):
+                raise FileNotFoundError(f"Config file not found: {cfg}")
+        else:
+            wf = Path(resolved)
+            cfg = next((os.fspath(c) for c in (wf.with_suffix(".json"), wf.parent / "config.json") if c.exists()), None)
+        return resolved, cfg
+
+    # ------------------------------------------------------------------------------------- preprocessing
+    def _load_rgb(self, image) -> np.ndarray:
+        if isinstance(image, str):
+            if not os.path.exists(image):
+                raise FileNotFoundError(f"Image file not found: {image}")
+            try:
+                with Image.open(image) as im:
+                    return np.array(im.convert("RGB"))
+            except Exception:
+                raise ValueError(f"Cannot read image: {image}")
+        if isinstance(image, Image.Image):
+            return np.array(image.convert("RGB"))
+        if isinstance(image, np.ndarray):
+            return image
+        raise ValueError(f"Unsupported image type: {type(image)}")
+
+    def _canvases(self, images) -> np.ndarray:
+        """ResizeAndPadA on the host (u8), one [img_h, img_w, 3] canvas per crop."""
+        return np.stack([resize_and_pad(self._load_rgb(im), self.img_h, self.img_w) for im in images])
+
+    # ------------------------------------------------------------------------------------- device path
+    def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9):
+        """canvases [N,img_h,img_w,3] u8 on device -> (logits [N,steps,V] f32, ids [N,steps] i32, t_run [N]) on host."""
+        N = canvases_dev.shape[0]
+        outs_l, outs_i, outs_t = [], [], []
+        for s in range(0, N, self.device_batch):
+            cv = canvases_dev[s:s + self.device_batch]
+            B = cv.shape[0]
+            batch_H, proj_H = self.model.encode(cv)
+            if mode == "greedy":
+                logits, ids = self.model.greedy(batch_H, proj_H, self.max_length, self.sos_id, self.eos_id, self.blank_id)
+                ids_h = ids.cpu().numpy()
+                trun = np.empty(B, dtype=np.int32)
+                for c0 in range(0, B, batch_size):  # reference chunk: stops at the first step where EVERY row emits EOS
+                    all_eos = np.all(ids_h[c0:c0 + batch_size] == self.eos_id, axis=0)
+                    hit = np.nonzero(all_eos)[0]
+                    trun[c0:c0 + batch_size] = (hit[0] + 1) if len(hit) else ids_h.shape[1]
+                outs_l.append(logits.cpu().numpy()), outs_i.append(ids_h), outs_t.append(trun)
+            elif mode == "beam":
+                ws, fin, _ = self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
+                                             self.blank_id)
+                fin_h = fin.cpu().numpy()
+                trun = np.empty(B, dtype=np.int32)
+                for c0 in range(0, B, batch_size):  # reference chunk: stops once every beam of every row is finished
+                    trun[c0:c0 + batch_size] = fin_h[c0:c0 + batch_size].max()
+                logits, ids = self.model.beam_finalize(ws, B, self.max_length, beam_size, torch.from_numpy(trun).to(self.device))
+                outs_l.append(logits.cpu().numpy()), outs_i.append(ids.cpu().numpy()), outs_t.append(trun)
+            else:
+                raise ValueError(f"Unknown mode: {mode}")
+        return np.concatenate(outs_l), np.concatenate(outs_i), np.concatenate(outs_t)
+
+    def _results(self, logits, ids, trun) -> List[Dict[str, Any]]:
+        """__init__.py:413-432: log_softmax, decode_tokens, confidence = mean over ALL generated positions."""
+        res = []
+        for j in range(len(ids)):
+            t = int(trun[j])
+            row = ids[j, :t]
+            x = logits[j, :t].astype(np.float32)
+            m = x.max(axis=-1, keepdims=True)
+            logp = x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=np.float32))
+            text = decode_tokens(row, self.itos, self.pad_id, self.eos_id, self.blank_id)
+            conf = float(np.exp(logp[np.arange(t), row]).mean(dtype=np.float32)) if t > 0 else 0.0
+            res.append({"text": text, "confidence": conf})
+        return res
+
+    # ------------------------------------------------------------------------------------- API
+    def predict(self, images, batch_size: int = 32, mode: str = "beam", beam_size: int = 8, temperature: float = 1.7,
+                alpha: float = 0.9) -> List[Dict[str, Any]]:
+        """Same contract as the reference TRBA.predict (__init__.py:290-434)."""
+        images_list = images if isinstance(images, list) else [images]
+        if mode not in ("greedy", "beam"):
+            raise ValueError(f"Unknown mode: {mode}")
+        if not images_list:
+            return []
+        canv = torch.from_numpy(self._canvases(images_list)).to(self.device, non_blocking=True)
+        logits, ids, trun = self.recognize_canvases(canv, batch_size, mode, beam_size, temperature, alpha)
+        return self._results(logits, ids, trun)

@@ -62,12 +62,18 @@ def synth_maps(rects, page_hw, map_hw, seed, noise=0.05):
         ys, xs = ys[(ys >= 0) & (ys < mh)], xs[(xs >= 0) & (xs < mw)]
         if len(ys) == 0 or len(xs) == 0:
             continue
+        corners = [(a, b), (c, b), (c, d), (a, d)]  # TL, TR, BR, BL
+        # geometry is valid on the text region AND a 2-px ring around it (a trained EAST regresses sensible
+        # offsets next to text too); only the score separates text from background.  Without the ring the
+        # quantised cell centres (utils.py:349-356) that fall just outside a word would decode noise quads.
+        gy = np.arange(max(ys[0] - 2, 0), min(ys[-1] + 3, mh))
+        gx = np.arange(max(xs[0] - 2, 0), min(xs[-1] + 3, mw))
+        gyy, gxx = np.meshgrid(gy, gx, indexing="ij")
+        for i, (vx, vy) in enumerate(corners):
+            geo[gyy, gxx, 2 * i] = (vx - gxx + rng.normal(0, noise, gyy.shape)).astype(np.float32)
+            geo[gyy, gxx, 2 * i + 1] = (vy - gyy + rng.normal(0, noise, gyy.shape)).astype(np.float32)
         yy, xx = np.meshgrid(ys, xs, indexing="ij")
         score[yy, xx] = (0.9 + 0.05 * rng.random(yy.shape)).astype(np.float32)
-        corners = [(a, b), (c, b), (c, d), (a, d)]  # TL, TR, BR, BL
-        for i, (vx, vy) in enumerate(corners):
-            geo[yy, xx, 2 * i] = (vx - xx + rng.normal(0, noise, yy.shape)).astype(np.float32)
-            geo[yy, xx, 2 * i + 1] = (vy - yy + rng.normal(0, noise, yy.shape)).astype(np.float32)
     return score, geo
 
 
