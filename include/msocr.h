@@ -144,8 +144,14 @@ int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_
 int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                              float* logits_out, int32_t* ids_out, void* stream);
 
-/* u8 crops -> normalised TRBA batch (ResizeAndPadA+Normalize, recognizers/_trba/data/transforms.py:62-120,185-193)
- * from boxes of a device-resident page: next-round item; round 1 preprocesses crops on the host. */
+/* Word crops -> recogniser canvases on the device: clamped AABB crop (Pipeline._extract_word_image,
+ * _pipeline.py:204-221) + ResizeAndPadA (recognizers/_trba/data/transforms.py:85-120: aspect-preserving resize,
+ * INTER_AREA if any axis shrinks else INTER_LINEAR, pasted at x=0 / vertically centred on a 255 canvas).
+ * pages [N][H][W][3] u8; descriptor per crop = 8 x int32 {page, x1, y1, x2, y2, new_w, new_h, y0} (the host
+ * evaluates Python's banker's rounding of the new size); desc_host is the same array in host memory, used only
+ * to validate bounds before the launch.  canvases [M][img_h][img_w][3] u8.  (cv2 restated: parity unpinned.) */
+int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32_t* desc_dev,
+                          const int32_t* desc_host, int M, int img_h, int img_w, uint8_t* canvases, void* stream);
 
 /* f32 <-> bf16 / layout helpers */
 int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int W, int dtype, void* out, int64_t out_ld,

@@ -113,28 +113,62 @@ class Pipeline:
             return page, visualize_page(pil, page, show_order=True)
         return page
 
-    def predict_batch(self, images: List[Union[str, np.ndarray]], recognize_text: bool = True, profile: bool = False):
-        """Equally sized pages -> list of Pages: one detector pass for the batch, one recogniser pass for all crops."""
-        if not (hasattr(self.detector, "predict_batch") and isinstance(self.detector, EAST)):
+    def predict_batch(self, images: List[Union[str, np.ndarray]], recognize_text: bool = True, profile: bool = False,
+                      pages_dev=None, _maps_override=None):
+        """Equally sized pages -> list of Pages, same results as per-page `predict`.
+
+        MI355X fast path (detector and recogniser are this package's EAST / TRBA): the pages are uploaded once,
+        the detector runs once for the batch, word crops are cut, resized and padded ON THE DEVICE from the resident
+        pages (no host crop, no per-crop upload) and the recogniser runs once over all crops of all pages — while the
+        decode run lengths that enter the confidences still follow the reference's per-page / per-`batch_size` chunking.
+        `pages_dev`: optional [N,H,W,3] u8 device tensor already holding `images` (benchmarks: inputs resident in HBM)."""
+        native = isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA)
+        if not native:
             return [self.predict(im, recognize_text=recognize_text, profile=profile) for im in images]
+        import torch
+
+        from . import ops
         arrays = [read_image(im) for im in images]
-        pages = [self._page_of(r) for r in self.detector.predict_batch(arrays, profile=profile)]
+        if pages_dev is None:
+            pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(self.detector.device)
+        results = self.detector.predict_batch(arrays, profile=profile, _pages_dev=pages_dev, _maps_override=_maps_override)
+        pages = [self._page_of(r) for r in results]
         if not recognize_text:
             return pages
-        all_words, all_crops, spans = [], [], []
-        for page, arr in zip(pages, arrays):
-            words, crops = self._order_and_crop(page, arr)
-            spans.append((len(all_words), len(words)))
-            all_words += words
-            all_crops += crops
-        if all_crops:
-            # per page the reference calls recognizer.predict(crops) separately: its batch_size chunks (and hence the
-            # decode run length that enters the confidences) restart at every page -> keep that chunking.
-            results = []
-            for s, n in spans:
-                if n:
-                    results += self.recognizer.predict(all_crops[s:s + n])
-            self._assign(all_words, results)
+        rec = self.recognizer
+        all_words, boxes, page_ids, spans = [], [], [], []
+        for pi, page in enumerate(pages):
+            n0 = len(all_words)
+            for block in page.blocks:
+                aabbs = [_word_aabb(w)[0] for w in block.words]
+                new_order = []
+                for bx in sort_boxes_reading_order_with_resolutions(aabbs):
+                    for w, wb in zip(block.words, aabbs):
+                        if wb == bx:
+                            new_order.append(w)
+                            break
+                block.words = new_order
+                for word in block.words:
+                    (x0, y0, x1, y1), _ = _word_aabb(word)
+                    if (x1 - x0) >= self.min_text_size and (y1 - y0) >= self.min_text_size:
+                        all_words.append(word), boxes.append((x0, y0, x1, y1)), page_ids.append(pi)
+            spans.append([n0, len(all_words) - n0])
+        if not boxes:
+            return pages
+        H, W = arrays[0].shape[:2]
+        desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
+        if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
+            all_words = [w for w, k in zip(all_words, keep) if k]
+            kept_pages = np.asarray(page_ids)[keep]
+            spans, n0 = [], 0
+            for pi in range(len(pages)):
+                c = int((kept_pages == pi).sum())
+                spans.append([n0, c])
+                n0 += c
+        if len(desc):
+            canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
+            logits, ids, trun = rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])
+            self._assign(all_words, rec._results(logits, ids, trun))
         return pages
 
     def process_batch(self, images: List[Union[str, np.ndarray, Image.Image]], recognize_text: bool = True, vis: bool = False,

@@ -364,3 +364,135 @@ extern "C" int msocr_nhwc_to_nchw_f32(const void* in, int N, int C, int H, int W
 }
 
 extern "C" const char* msocr_version(void) { return "msocr 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------
+// Crop + ResizeAndPadA on the device (recognizers/_trba/data/transforms.py:85-120 applied to the clamped
+// AABB views of _pipeline.py:204-221): one workgroup per crop, one canvas pixel (3 channels) per thread
+// iteration.  cv2.resize semantics restated from OpenCV (parity unpinned, cv2 absent): INTER_AREA =
+// float area tables accumulated in table order (x inside y), integer-scale fast path; INTER_LINEAR =
+// 11-bit fixed point.  Descriptor per crop (8 x int32): page, x1, y1, x2, y2, new_w, new_h, y0.
+__device__ __forceinline__ uint8_t sat_u8_rint(float v) {
+  const float r = rintf(v);
+  return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+
+struct AreaTab {  // up to 3 kinds of entries for one destination index: head partial, full run, tail partial
+  int s_head, s1, s2;
+  float a_head, a_full, a_tail;
+  bool has_head, has_tail;
+};
+__device__ __forceinline__ AreaTab area_tab(int d, double scale, int ssize) {
+  AreaTab t;
+  const double f1 = d * scale, f2 = f1 + scale;
+  const double cell = fmin(scale, (double)ssize - f1);
+  int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+  s2 = s2 < ssize - 1 ? s2 : ssize - 1;
+  s1 = s1 < s2 ? s1 : s2;
+  t.s1 = s1;
+  t.s2 = s2;
+  t.has_head = (s1 - f1) > 1e-3;
+  t.s_head = s1 - 1;
+  t.a_head = (float)((s1 - f1) / cell);
+  t.a_full = (float)(1.0 / cell);
+  t.has_tail = (f2 - s2) > 1e-3;
+  t.a_tail = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_pad_kernel(const uint8_t* __restrict__ pages, int H, int W,
+                                                               const int32_t* __restrict__ desc, int img_h, int img_w,
+                                                               uint8_t* __restrict__ out) {
+  const int m = blockIdx.x;
+  const int32_t* d = desc + (long)m * 8;
+  const int pg = d[0], x1 = d[1], y1 = d[2], x2 = d[3], y2 = d[4], nw = d[5], nh = d[6], y0 = d[7];
+  const int sw = x2 - x1, sh = y2 - y1;
+  const uint8_t* src = pages + ((long)pg * H + y1) * W * 3 + (long)x1 * 3;
+  const long rs = (long)W * 3;  // source row stride in bytes
+  uint8_t* o = out + (long)m * img_h * img_w * 3;
+  const bool shrink = nh < sh || nw < sw;
+  const bool copy = nw == sw && nh == sh;
+  const bool area = shrink && !copy && !(nw > sw || nh > sh);
+  const bool area_int = area && (sw % nw == 0) && (sh % nh == 0);
+  const double scale_x = (double)sw / (double)nw, scale_y = (double)sh / (double)nh;
+  const double lin_sx = 1.0 / ((double)nw / (double)sw), lin_sy = 1.0 / ((double)nh / (double)sh);
+  for (int p = threadIdx.x; p < img_h * img_w; p += blockDim.x) {
+    const int cy = p / img_w, cx = p - cy * img_w;
+    const int dy = cy - y0, dx = cx;
+    uint8_t r[3] = {255, 255, 255};
+    if (dy >= 0 && dy < nh && dx < nw) {
+      if (copy) {
+        const uint8_t* s = src + dy * rs + dx * 3;
+        r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
+      } else if (area_int) {
+        const int kx = sw / nw, ky = sh / nh;
+        int acc[3] = {0, 0, 0};
+        for (int yy = 0; yy < ky; ++yy) {
+          const uint8_t* s = src + (long)(dy * ky + yy) * rs + (long)dx * kx * 3;
+          for (int xx = 0; xx < kx; ++xx)
+            for (int c = 0; c < 3; ++c) acc[c] += s[xx * 3 + c];
+        }
+        if (kx == 2 && ky == 2) {
+          for (int c = 0; c < 3; ++c) r[c] = (uint8_t)((acc[c] + 2) >> 2);
+        } else {
+          const float inv = (float)(1.0 / (double)(kx * ky));
+          for (int c = 0; c < 3; ++c) r[c] = sat_u8_rint((float)acc[c] * inv);
+        }
+      } else if (area) {
+        const AreaTab tx = area_tab(dx, scale_x, sw), ty = area_tab(dy, scale_y, sh);
+        float sum[3] = {0.f, 0.f, 0.f};
+        auto row = [&](int sy, float beta) {
+          const uint8_t* s = src + (long)sy * rs;
+          float buf[3] = {0.f, 0.f, 0.f};
+          if (tx.has_head)
+            for (int c = 0; c < 3; ++c) buf[c] += (float)s[tx.s_head * 3 + c] * tx.a_head;
+          for (int sx = tx.s1; sx < tx.s2; ++sx)
+            for (int c = 0; c < 3; ++c) buf[c] += (float)s[sx * 3 + c] * tx.a_full;
+          if (tx.has_tail)
+            for (int c = 0; c < 3; ++c) buf[c] += (float)s[tx.s2 * 3 + c] * tx.a_tail;
+          for (int c = 0; c < 3; ++c) sum[c] += buf[c] * beta;
+        };
+        if (ty.has_head) row(ty.s_head, ty.a_head);
+        for (int sy = ty.s1; sy < ty.s2; ++sy) row(sy, ty.a_full);
+        if (ty.has_tail) row(ty.s2, ty.a_tail);
+        for (int c = 0; c < 3; ++c) r[c] = sat_u8_rint(sum[c]);
+      } else {  // INTER_LINEAR fixed point
+        float fx = (float)((dx + 0.5) * lin_sx - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+        const int a0 = rint_short((1.f - fx) * 2048.f), a1 = rint_short(fx * 2048.f);
+        const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+        float fy = (float)((dy + 0.5) * lin_sy - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const int b0 = rint_short((1.f - fy) * 2048.f), b1 = rint_short(fy * 2048.f);
+        const int r0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        const int r1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const uint8_t* q0 = src + (long)r0 * rs;
+        const uint8_t* q1 = src + (long)r1 * rs;
+        for (int c = 0; c < 3; ++c) {
+          const int S0 = q0[sx * 3 + c] * a0 + q0[sx1 * 3 + c] * a1;
+          const int S1 = q1[sx * 3 + c] * a0 + q1[sx1 * 3 + c] * a1;
+          const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+          r[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+      }
+    }
+    o[(long)p * 3] = r[0];
+    o[(long)p * 3 + 1] = r[1];
+    o[(long)p * 3 + 2] = r[2];
+  }
+}
+
+extern "C" int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32_t* desc_dev, const int32_t* desc_host,
+                                     int M, int img_h, int img_w, uint8_t* canvases, void* stream) {
+  if (!pages || !desc_dev || !desc_host || !canvases || N <= 0 || H <= 0 || W <= 0 || M <= 0 || img_h <= 0 || img_w <= 0) return MSOCR_E_ARG;
+  for (int m = 0; m < M; ++m) {  // validate on the host what the kernel's indexing assumes
+    const int32_t* d = desc_host + (long)m * 8;
+    if (d[0] < 0 || d[0] >= N || d[1] < 0 || d[2] < 0 || d[3] > W || d[4] > H || d[3] <= d[1] || d[4] <= d[2]) return MSOCR_E_ARG;
+    if (d[5] < 1 || d[5] > img_w || d[6] < 1 || d[6] > img_h || d[7] < 0 || d[7] + d[6] > img_h) return MSOCR_E_ARG;
+  }
+  MSOCR_LAUNCH(crop_resize_pad_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, pages, H, W, desc_dev, img_h, img_w, canvases);
+  return LAUNCH_OK();
+}

@@ -141,12 +141,13 @@ class EAST:
 
     # ------------------------------------------------------------------------------------- API
     def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
-                      sort_reading_order=False, _maps_override=None) -> List[Dict[str, Any]]:
+                      sort_reading_order=False, _maps_override=None, _pages_dev=None) -> List[Dict[str, Any]]:
         imgs = [read_image(im) for im in images]
         if len({im.shape for im in imgs}) != 1:
             raise ValueError("predict_batch needs equally sized pages")
         t0 = time.time()
-        pages = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
+        pages = _pages_dev if _pages_dev is not None else \
+            torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
         score, geo, boxes, nbox, counts = self.detect_device(pages, _maps_override)
         nbox_h = nbox.cpu().numpy()
         counts_h = counts.cpu().numpy()

@@ -59,25 +59,25 @@ def quad_areas(pts):
     return 0.5 * np.abs(np.sum(x * np.roll(y, -1, axis=1) - y * np.roll(x, -1, axis=1), axis=1))
 
 
-def _points_not_outside(px, py, contour):
-    """px, py: (P,) f32 points; contour (4,2) f32.  True where pointPolygonTest(...) >= 0."""
-    n = len(contour)
+def _pairs_not_outside(inner, outer):
+    """inner, outer: (P,4,2) f32.  -> (P,4) bool: vertex k of inner[p] is inside or on the boundary of outer[p],
+    i.e. cv2.pointPolygonTest(outer, pt, False) >= 0 (OpenCV's even-odd crossing rule, differences in f32,
+    products in f64, early return 0 on an exact edge hit)."""
+    px, py = inner[:, :, 0], inner[:, :, 1]  # (P,4)
     counter = np.zeros(px.shape, dtype=np.int64)
     on_edge = np.zeros(px.shape, dtype=bool)
-    done = np.zeros(px.shape, dtype=bool)  # OpenCV returns at the first on-edge hit
-    v = contour[n - 1]
-    for i in range(n):
-        v0, v = v, contour[i]
-        skip = ((v0[1] <= py) & (v[1] <= py)) | ((v0[1] > py) & (v[1] > py)) | ((v0[0] < px) & (v[0] < px))
-        hit = skip & (py == v[1]) & ((px == v[0]) | ((py == v0[1]) & (((v0[0] <= px) & (px <= v[0])) | ((v[0] <= px) & (px <= v0[0])))))
-        dist = (py - v0[1]).astype(np.float64) * np.float64(v[0] - v0[0]) - (px - v0[0]).astype(np.float64) * np.float64(v[1] - v0[1])
+    for i in range(4):
+        v0 = outer[:, (i - 1) % 4][:, None, :]  # (P,1,2)
+        v = outer[:, i][:, None, :]
+        v0x, v0y, vx, vy = v0[..., 0], v0[..., 1], v[..., 0], v[..., 1]
+        skip = ((v0y <= py) & (vy <= py)) | ((v0y > py) & (vy > py)) | ((v0x < px) & (vx < px))
+        hit = skip & (py == vy) & ((px == vx) | ((py == v0y) & (((v0x <= px) & (px <= vx)) | ((vx <= px) & (px <= v0x)))))
+        dist = (py - v0y).astype(np.float64) * (vx - v0x).astype(np.float64) - (px - v0x).astype(np.float64) * (vy - v0y).astype(np.float64)
         zero = ~skip & (dist == 0)
-        new_edge = (hit | zero) & ~done
-        on_edge |= new_edge
-        done |= new_edge
-        if v[1] < v0[1]:
-            dist = -dist
-        counter += (~skip & ~done & (dist > 0)).astype(np.int64)
+        live = ~on_edge  # OpenCV returns at the first on-edge hit
+        on_edge |= (hit | zero) & live
+        dist = np.where(vy < v0y, -dist, dist)
+        counter += (~skip & live & ~zero & (dist > 0)).astype(np.int64)
     return on_edge | (counter % 2 == 1)
 
 
@@ -88,20 +88,16 @@ def remove_contained(quads):
         return quads
     pts = quads[:, :8].reshape(-1, 4, 2).astype(np.float32)
     areas = quad_areas(quads[:, :8].reshape(-1, 4, 2))
-    # inside[i, j]: all vertices of i are not outside j  (M x M, M is a few hundred)
+    # inside[i, j]: all vertices of i are not outside j.  Bounding-box prefilter first (a vertex outside j's
+    # bbox is outside j), then the surviving (i, j) pairs in one vectorised even-odd evaluation.
     inside = np.zeros((m, m), dtype=bool)
-    px, py = pts[:, :, 0].reshape(-1), pts[:, :, 1].reshape(-1)
-    # cheap bounding-box prefilter: a vertex outside j's bbox is outside j
     bx0, bx1 = pts[:, :, 0].min(1), pts[:, :, 0].max(1)
     by0, by1 = pts[:, :, 1].min(1), pts[:, :, 1].max(1)
     cand = (bx0[:, None] >= bx0[None, :]) & (bx1[:, None] <= bx1[None, :]) & (by0[:, None] >= by0[None, :]) & (by1[:, None] <= by1[None, :])
-    for j in range(m):
-        idx = np.nonzero(cand[:, j])[0]
-        if len(idx) == 0:
-            continue
-        sel = (idx[:, None] * 4 + np.arange(4)[None, :]).reshape(-1)
-        ok = _points_not_outside(px[sel], py[sel], pts[j]).reshape(-1, 4).all(axis=1)
-        inside[idx[ok], j] = True
+    np.fill_diagonal(cand, False)
+    ii, jj = np.nonzero(cand)
+    if len(ii):
+        inside[ii, jj] = _pairs_not_outside(pts[ii], pts[jj]).all(axis=1)
     keep = np.ones(m, dtype=bool)
     np.fill_diagonal(inside, False)
     big_enough = (areas[None, :] + 1e-6) >= areas[:, None]  # [i, j]: j may contain i

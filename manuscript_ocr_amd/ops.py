@@ -218,3 +218,43 @@ def bilstm_recurrent(xproj, whh_t, B, T, H):
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=xproj.device)
     nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
     return out
+
+
+def crop_descriptors(boxes, page_ids, page_hw, img_h, img_w):
+    """Host side of the device crop: clamped AABB (reference _pipeline.py:211-217) and ResizeAndPadA's size
+    arithmetic (transforms.py:91-95,114-117; Python round = banker's).  boxes: iterable of (x_min,y_min,x_max,y_max)
+    ints.  Returns (int32 [M,8] descriptors, keep mask) — empty crops are dropped like the reference does."""
+    import numpy as np
+    H, W = page_hw
+    desc, keep = [], []
+    for (x0, y0, x1, y1), pg in zip(boxes, page_ids):
+        a, b = max(0, int(x0)), max(0, int(y0))
+        c, d = min(W, int(x1)), min(H, int(y1))
+        if c < 0:  # Python slice semantics of image[y1:y2, x1:x2] with a negative stop
+            c = max(W + c, 0)
+        if d < 0:
+            d = max(H + d, 0)
+        if c <= a or d <= b:
+            keep.append(False)
+            continue
+        h, w = d - b, c - a
+        scale = min(img_h / max(h, 1), img_w / max(w, 1))
+        nw, nh = max(1, int(round(w * scale))), max(1, int(round(h * scale)))
+        yy = max(0, min((img_h - nh) // 2, img_h - nh))
+        desc.append((pg, a, b, c, d, nw, nh, yy))
+        keep.append(True)
+    return np.asarray(desc, dtype=np.int32).reshape(-1, 8), np.asarray(keep, dtype=bool)
+
+
+def crop_resize_pad(pages_u8, desc_host, img_h, img_w):
+    """pages [N,H,W,3] u8 device, desc_host int32 [M,8] (numpy) -> canvases [M,img_h,img_w,3] u8 device."""
+    _need_cuda(pages_u8)
+    N, H, W, C = pages_u8.shape
+    assert C == 3 and pages_u8.dtype == torch.uint8 and pages_u8.is_contiguous()
+    M = len(desc_host)
+    desc_host = desc_host.astype("int32", copy=False)
+    desc_dev = torch.from_numpy(desc_host).to(pages_u8.device)
+    out = torch.empty((M, img_h, img_w, 3), dtype=torch.uint8, device=pages_u8.device)
+    nat.check(nat.lib().msocr_crop_resize_pad(pages_u8.data_ptr(), N, H, W, desc_dev.data_ptr(), desc_host.ctypes.data, M, img_h, img_w,
+                                              out.data_ptr(), _stream()), "crop_resize_pad")
+    return out

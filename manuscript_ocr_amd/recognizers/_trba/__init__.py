@@ -134,35 +134,50 @@ class TRBA:
         return np.stack([resize_and_pad(self._load_rgb(im), self.img_h, self.img_w) for im in images])
 
     # ------------------------------------------------------------------------------------- device path
-    def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9):
-        """canvases [N,img_h,img_w,3] u8 on device -> (logits [N,steps,V] f32, ids [N,steps] i32, t_run [N]) on host."""
+    def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
+                           spans=None):
+        """canvases [N,img_h,img_w,3] u8 on device -> (logits [N,steps,V] f32, ids [N,steps] i32, t_run [N]) on host.
+
+        `spans` = [(start, count), ...] groups of rows that the reference would have passed to ONE predict() call
+        (one page each); inside a span rows are chunked by `batch_size` and every chunk stops at its own step
+        (greedy: first step where every row emits EOS; beam: once every beam of every row is finished) — that run
+        length enters the confidences.  The device batches (`device_batch` rows) are independent of that chunking."""
+        if mode not in ("greedy", "beam"):
+            raise ValueError(f"Unknown mode: {mode}")
         N = canvases_dev.shape[0]
-        outs_l, outs_i, outs_t = [], [], []
-        for s in range(0, N, self.device_batch):
+        spans = spans if spans is not None else [(0, N)]
+        steps = self.max_length + 1 if mode == "greedy" else self.max_length
+        parts = []
+        for s in range(0, N, self.device_batch):  # phase 1: encode + full-length decode, results stay on the device
             cv = canvases_dev[s:s + self.device_batch]
-            B = cv.shape[0]
             batch_H, proj_H = self.model.encode(cv)
             if mode == "greedy":
-                logits, ids = self.model.greedy(batch_H, proj_H, self.max_length, self.sos_id, self.eos_id, self.blank_id)
-                ids_h = ids.cpu().numpy()
-                trun = np.empty(B, dtype=np.int32)
-                for c0 in range(0, B, batch_size):  # reference chunk: stops at the first step where EVERY row emits EOS
-                    all_eos = np.all(ids_h[c0:c0 + batch_size] == self.eos_id, axis=0)
-                    hit = np.nonzero(all_eos)[0]
-                    trun[c0:c0 + batch_size] = (hit[0] + 1) if len(hit) else ids_h.shape[1]
-                outs_l.append(logits.cpu().numpy()), outs_i.append(ids_h), outs_t.append(trun)
-            elif mode == "beam":
-                ws, fin, _ = self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
-                                             self.blank_id)
-                fin_h = fin.cpu().numpy()
-                trun = np.empty(B, dtype=np.int32)
-                for c0 in range(0, B, batch_size):  # reference chunk: stops once every beam of every row is finished
-                    trun[c0:c0 + batch_size] = fin_h[c0:c0 + batch_size].max()
-                logits, ids = self.model.beam_finalize(ws, B, self.max_length, beam_size, torch.from_numpy(trun).to(self.device))
-                outs_l.append(logits.cpu().numpy()), outs_i.append(ids.cpu().numpy()), outs_t.append(trun)
+                parts.append(self.model.greedy(batch_H, proj_H, self.max_length, self.sos_id, self.eos_id, self.blank_id))
             else:
-                raise ValueError(f"Unknown mode: {mode}")
-        return np.concatenate(outs_l), np.concatenate(outs_i), np.concatenate(outs_t)
+                parts.append(self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
+                                             self.blank_id))
+        trun = np.empty(N, dtype=np.int32)  # phase 2: the reference's per-chunk run length
+        if mode == "greedy":
+            ids_h = np.concatenate([p[1].cpu().numpy() for p in parts])
+            for s0, cnt in spans:
+                for c0 in range(s0, s0 + cnt, batch_size):
+                    c1 = min(c0 + batch_size, s0 + cnt)
+                    hit = np.flatnonzero(np.all(ids_h[c0:c1] == self.eos_id, axis=0))
+                    trun[c0:c1] = (hit[0] + 1) if len(hit) else steps
+            logits_h = np.concatenate([p[0].cpu().numpy() for p in parts])
+            return logits_h, ids_h, trun
+        fin_h = np.concatenate([p[1].cpu().numpy() for p in parts])
+        for s0, cnt in spans:
+            for c0 in range(s0, s0 + cnt, batch_size):
+                c1 = min(c0 + batch_size, s0 + cnt)
+                trun[c0:c1] = fin_h[c0:c1].max()
+        trun_dev = torch.from_numpy(trun).to(self.device)
+        outs_l, outs_i = [], []
+        for k, s in enumerate(range(0, N, self.device_batch)):  # phase 3: back-track every row at its chunk's run length
+            B = min(self.device_batch, N - s)
+            lg, ids = self.model.beam_finalize(parts[k][0], B, steps, beam_size, trun_dev[s:s + B])
+            outs_l.append(lg.cpu().numpy()), outs_i.append(ids.cpu().numpy())
+        return np.concatenate(outs_l), np.concatenate(outs_i), trun
 
     def _results(self, logits, ids, trun) -> List[Dict[str, Any]]:
         """__init__.py:413-432: log_softmax, decode_tokens, confidence = mean over ALL generated positions."""

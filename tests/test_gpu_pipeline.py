@@ -1,0 +1,132 @@
+"""End-to-end Pipeline on the MI355X vs the oracle's CPU restatement of the whole reference path
+(EAST post-processing -> reading order -> crops -> ResizeAndPadA -> TRBA beam decode -> text)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CHARSET = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "manuscript_ocr_amd", "recognizers", "_trba",
+                       "configs", "charset.txt")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_crop_resize_pad_bit_exact_vs_oracle(gpu):
+    from manuscript_ocr_amd import ops
+    from oracle import imgproc
+    rng = np.random.default_rng(4)
+    pages = rng.integers(0, 256, size=(2, 300, 500, 3), dtype=np.uint8)
+    boxes, pids = [], []
+    for (w, h) in ((120, 28), (100, 32), (50, 16), (200, 64), (300, 96), (33, 57), (400, 20), (7, 9), (250, 31), (99, 33), (128, 32),
+                   (64, 64), (480, 290), (10, 200)):
+        x0, y0 = int(rng.integers(0, 500 - w)), int(rng.integers(0, 300 - h))
+        boxes.append((x0, y0, x0 + w, y0 + h))
+        pids.append(int(rng.integers(0, 2)))
+    boxes.append((-5, -7, 60, 40))   # clamped at the page border
+    pids.append(0)
+    boxes.append((450, 280, 520, 330))
+    pids.append(1)
+    for (ih, iw) in ((32, 100), (64, 256), (32, 128)):
+        desc, keep = ops.crop_descriptors(boxes, pids, (300, 500), ih, iw)
+        assert keep.all()
+        got = ops.crop_resize_pad(torch.from_numpy(pages).cuda(), desc, ih, iw).cpu().numpy()
+        for k, ((x0, y0, x1, y1), pg) in enumerate(zip(boxes, pids)):
+            crop = pages[pg][max(0, y0):min(300, y1), max(0, x0):min(500, x1)]
+            exp = imgproc.resize_and_pad(crop, ih, iw)
+            assert np.array_equal(got[k], exp), (k, boxes[k], ih, iw, np.abs(got[k].astype(int) - exp.astype(int)).max())
+
+
+def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5):
+    """The reference path on the CPU: infer.py:319-363 + _pipeline.py:100-162 + TRBA.predict (beam defaults)."""
+    from oracle import east_post as P
+    from oracle import imgproc
+    from oracle import lanms as L
+    from oracle import pipeline_glue as G
+    from oracle import trba_model as otm
+    H, W = page.shape[:2]
+    quads = P.east_postprocess(score, geo, (H, W), (W, H), L.locality_aware_nms)
+    polys = [q[:8].reshape(4, 2).tolist() for q in quads]
+    order, kept, crops = G.order_and_crop(polys, page, min_text_size)
+    res = []
+    for c0 in range(0, len(crops), 32):
+        x = torch.from_numpy(np.stack([imgproc.trba_preprocess(c, cfg["img_h"], cfg["img_w"]) for c in crops[c0:c0 + 32]]))
+        with torch.no_grad():
+            lg, ids = trba_net(x, max_len=cfg["max_len"], mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
+        res += otm.texts_and_confidences(lg, ids, itos, 0, 2, None)
+    words = [{"polygon": polys[wi], "det": float(quads[wi][8]), "text": None, "rec": None} for wi in order]
+    for pos, r in zip(kept, res):
+        words[pos]["text"], words[pos]["rec"] = r["text"], r["confidence"]
+    return words
+
+
+def test_pipeline_end_to_end_matches_oracle(gpu):
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import east_model as oem
+    from oracle import trba_model as otm
+    H, W = 512, 768
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    tsd = otm.synth_trba_state_dict(194, 256, seed=20260128)
+    det = EAST(state_dict=oem.synth_east_state_dict(), target_size=(W, H), device="cuda")
+    rec = TRBA(state_dict=tsd, config=cfg, device="cuda")
+    pipe = Pipeline(detector=det, recognizer=rec)
+    pages, maps = [], []
+    for seed in (41, 42):
+        pg, rects = synth.synth_page(seed, H, W)
+        pages.append(pg)
+        maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+    mo = (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())
+    got_pages = pipe.predict_batch(pages, _maps_override=mo)
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(tsd)
+    ref_net.eval()
+    itos, _ = otm.load_charset(CHARSET)
+    n_text = 0
+    for pg, (s, g), got in zip(pages, maps, got_pages):
+        exp = _oracle_pipeline(pg, s, g, ref_net, itos, cfg)
+        gw = got.blocks[0].words
+        assert len(gw) == len(exp) and len(exp) > 20
+        for a, b in zip(gw, exp):
+            assert [tuple(p) for p in a.polygon] == [tuple(p) for p in b["polygon"]]
+            assert a.detection_confidence == b["det"]
+            assert a.text == b["text"]          # CER of HIP text vs CPU text == 0
+            if b["rec"] is None:
+                assert a.recognition_confidence is None
+            else:
+                assert abs(a.recognition_confidence - b["rec"]) < 1e-4
+                n_text += 1
+        assert pipe.get_text(got).count(" ") > 5
+    assert n_text > 40
+
+
+def test_predict_batch_equals_per_page_predict(gpu):
+    """The batched device-crop fast path and the generic plugin path (host crops, per-page calls) agree."""
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import east_model as oem
+    from oracle import trba_model as otm
+    H, W = 256, 384
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    det = EAST(state_dict=oem.synth_east_state_dict(), target_size=(W, H), device="cuda", score_thresh=0.5)
+    rec = TRBA(state_dict=otm.synth_trba_state_dict(194, 256, seed=3), config=cfg, device="cuda")
+    pipe = Pipeline(detector=det, recognizer=rec)
+    pages = [synth.synth_page(s, H, W)[0] for s in (1, 2, 3)]
+    a = pipe.predict_batch(pages)
+    b = [pipe.predict(p) for p in pages]
+    assert sum(len(p.blocks[0].words) for p in a) > 0, "random-weight maps produced no boxes; lower score_thresh"
+    for pa, pb in zip(a, b):
+        assert [w.polygon for w in pa.blocks[0].words] == [w.polygon for w in pb.blocks[0].words]
+        assert [w.text for w in pa.blocks[0].words] == [w.text for w in pb.blocks[0].words]
+        ca = [w.recognition_confidence for w in pa.blocks[0].words]
+        cb = [w.recognition_confidence for w in pb.blocks[0].words]
+        assert all((x is None) == (y is None) for x, y in zip(ca, cb))
+        np.testing.assert_allclose([x for x in ca if x is not None], [y for y in cb if y is not None], atol=1e-6)

@@ -1,0 +1,145 @@
+"""CPU-only tests of the host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from manuscript_ocr_amd import _native
+    L = _native.lib()
+    header = open(os.path.join(ROOT, "include", "msocr.h")).read()
+    declared = set(re.findall(r"\b(msocr_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), f"libmsocr.so lacks {name} declared in include/msocr.h"
+    assert declared == set(_native.exported_symbols()), declared ^ set(_native.exported_symbols())
+    assert b"gfx950" in L.msocr_version()
+
+
+def test_native_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from manuscript_ocr_amd import _native, ops
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    with pytest.raises(RuntimeError):
+        EAST(state_dict={})
+    with pytest.raises(RuntimeError):
+        TRBA(state_dict={}, config={})
+    with pytest.raises(_native.NativeError):
+        ops.maxpool2d(torch.zeros(1, 4, 4, 4), 2, 2, 0)
+
+
+def test_error_contract_paths(tmp_path):
+    from manuscript_ocr_amd.detectors import read_image
+    from manuscript_ocr_amd.recognizers import TRBA
+    with pytest.raises(FileNotFoundError):
+        read_image(str(tmp_path / "missing.jpg"))
+    with pytest.raises(TypeError):
+        read_image(12345)
+    with pytest.raises(FileNotFoundError):
+        TRBA(model_path=str(tmp_path / "nope.pth"))
+    w = tmp_path / "w.pth"
+    w.write_bytes(b"x")
+    with pytest.raises(FileNotFoundError):
+        TRBA(model_path=str(w), config_path=str(tmp_path / "nope.json"))
+    with pytest.raises(FileNotFoundError):
+        TRBA(model_path=str(w), charset_path=str(tmp_path / "nope.txt"))
+    with pytest.raises(ValueError):
+        TRBA(model_path=str(w), weights_path=str(tmp_path / "other.pth"))
+    with pytest.raises(TypeError):
+        TRBA(model_path=str(w), bogus=1)
+
+
+def test_host_post_and_transforms_match_oracle(golden_dir):
+    from manuscript_ocr_amd.detectors._east import post as P
+    from manuscript_ocr_amd.recognizers._trba import transforms as T
+    from oracle import east_post as O
+    from oracle import imgproc
+    g = np.load(os.path.join(golden_dir, "east_post.npz"))
+    assert np.array_equal(P.expand_boxes(g["lanms_q2"], 0.9, 0.9).view(np.uint32), g["expanded"].view(np.uint32))
+    q = O.scale_boxes_to_original(g["expanded"], (1000, 1400), (1024, 768))
+    assert np.array_equal(P.scale_boxes(g["expanded"], (1000, 1400), (1024, 768)).view(np.uint32), q.view(np.uint32))
+    # nest a few quads inside existing ones (centre-shrunk copies, one touching an edge) so the filter has work
+    big = q[np.argsort(-O.polygon_area_batch(q[:, :8].reshape(-1, 4, 2)))[:6]].copy()
+    c = big[:, :8].reshape(-1, 4, 2).mean(axis=1, keepdims=True)
+    inner = big.copy()
+    inner[:, :8] = (c + 0.4 * (big[:, :8].reshape(-1, 4, 2) - c)).reshape(-1, 8)
+    inner[0, :2] = big[0, :2]  # shares a vertex with its container: on-edge counts as inside
+    q = np.concatenate([q, inner]).astype(np.float32)
+    a, b = O.remove_fully_contained_boxes(q), P.remove_contained(q)
+    assert len(a) < len(q) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(O.remove_area_anomalies(a).view(np.uint32), P.remove_area_anomalies(a).view(np.uint32))
+    assert np.array_equal(O.convert_to_axis_aligned(a).view(np.uint32), P.to_axis_aligned(a).view(np.uint32))
+    rng = np.random.default_rng(0)
+    for (h, w) in ((20, 44), (32, 100), (70, 300), (15, 15), (64, 500), (9, 200)):
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        for (ih, iw) in ((32, 100), (64, 256)):
+            assert np.array_equal(T.resize_and_pad(img, ih, iw), imgproc.resize_and_pad(img, ih, iw)), (h, w, ih, iw)
+    gray = rng.integers(0, 256, size=(20, 30), dtype=np.uint8)
+    assert T.resize_and_pad(gray, 32, 100).shape == (32, 100, 3)
+
+
+def test_pipeline_glue_matches_golden(golden_dir):
+    import json
+    from manuscript_ocr_amd.detectors import sort_boxes_reading_order, sort_boxes_reading_order_with_resolutions
+    from manuscript_ocr_amd.detectors._east.utils import resolve_intersections
+    for c in json.load(open(os.path.join(golden_dir, "pipeline_glue.json"))):
+        boxes = [tuple(np.int32(v) for v in b) for b in c["boxes"]]
+        assert [list(map(int, b)) for b in resolve_intersections(boxes)] == c["resolved"]
+        assert [list(map(int, b)) for b in sort_boxes_reading_order(boxes)] == c["sorted"]
+        assert [list(map(int, b)) for b in sort_boxes_reading_order_with_resolutions(boxes)] == c["sorted_res"]
+
+
+def test_shard_range_partitions():
+    from manuscript_ocr_amd.dist import shard_range
+    for n in (0, 1, 7, 16, 128, 129):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["REPO"])
+import torch, torch.distributed as dist
+from manuscript_ocr_amd.dist import shard_range, gather_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+lo, hi = shard_range(7, rank, world)
+local = [{"page": p, "word": 0, "text": "стр%d — ok" % p, "rec": 0.5 + p / 100} for p in range(lo, hi)]
+allr = gather_records(local, torch.device("cpu"))
+if rank == 0:
+    print("RESULT" + json.dumps(allr, ensure_ascii=False))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gather_records_world2_gloo(tmp_path):
+    """The N>1 exchange path (sizes all_gather + padded u8 all_gather) with 2 CPU ranks over gloo."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    import json
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0]
+    recs = json.loads(line[len("RESULT"):])
+    assert [r["page"] for r in recs] == list(range(7))
+    assert recs[5]["text"] == "стр5 — ok"
