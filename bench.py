@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py — manuscript pages/s on MI355X for the EAST(+TRBA) hot path.
+"""bench.py — manuscript pages/s on MI355X for the EAST + TRBA hot path.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic pages already resident in
-HBM (u8 pages + injected score/geo maps).  Pages shard across ranks with no
-data-path collective (weak scaling: the per-GPU batch is fixed); the only exchange is the
-final gather of result records (RCCL all_gather of a padded u8 buffer).  Rank 0 prints ONE
-JSON line with the whole-job pages/s, the live HIP-event roofline of the dominant kernel
-(implicit-GEMM convolution) and a bounded CPU baseline (the oracle, timed on the host cores).
+One "step" = one pass of the hot path over one batch of synthetic pages already resident in HBM
+(u8 pages + injected score/geo maps): Pipeline.predict_batch = EAST ResNet-50
+forward -> quad decode -> locality-aware NMS -> box filters -> reading order -> device crop +
+ResizeAndPadA -> TRBA SE-ResNet31 + BiLSTM + beam-8 attention decode -> text (workload
+"pipeline", BASELINE configs[3]); "--workload east" stops after the detector (configs[1]).
+Pages shard across ranks with no data-path collective (weak scaling: fixed per-GPU batch); the
+only exchange is the final gather of decoded records (all_gather of a padded u8 buffer over
+RCCL).  Rank 0 prints ONE JSON line: whole-job pages/s, the live HIP-event roofline of the
+dominant kernel (implicit-GEMM convolution on MFMA) and a bounded CPU baseline (the oracle =
+CPU restatement of the reference path, timed on the host cores).
 """
 import argparse
 import json
@@ -23,17 +27,19 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+TRBA_CFG = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="east", choices=["east", "pipeline"])
-    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--pages", type=int, default=8, help="pages per step per GPU")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="pipeline", choices=["east", "pipeline"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="conv storage/MFMA input type; fp32 = parity mode (text identical to the CPU reference)")
+    ap.add_argument("--pages", type=int, default=0, help="pages per step per GPU (default 16 pipeline / 8 east)")
     ap.add_argument("--height", type=int, default=1536)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,36 +60,43 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from manuscript_ocr_amd import ops, synth
+    from manuscript_ocr_amd import Pipeline, ops, synth
     from manuscript_ocr_amd.detectors import EAST
     from manuscript_ocr_amd.detectors._east.net import east_conv_macs
-    from oracle import east_model as oem  # synthetic-weight recipe shared with the CPU baseline
+    from manuscript_ocr_amd.dist import gather_records, page_records
+    from manuscript_ocr_amd.recognizers import TRBA
+    from manuscript_ocr_amd.recognizers._trba.net import trba_cnn_macs
+    from oracle import east_model as oem  # synthetic-weight recipes shared with the CPU baseline
+    from oracle import trba_model as otm
 
-    H, W, NP = a.height, a.width, a.pages
-    sd = oem.synth_east_state_dict(seed=20260128)
-    det = EAST(state_dict=sd, target_size=(W, H), device="cuda", precision=a.precision)
+    H, W = a.height, a.width
+    NP = a.pages or (16 if a.workload == "pipeline" else 8)
+    esd = oem.synth_east_state_dict(seed=20260128)
+    tsd = otm.synth_trba_state_dict(194, 256, seed=20260128)
+    det = EAST(state_dict=esd, target_size=(W, H), device="cuda", precision=a.precision)
+    rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
+    pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
 
-    # synthetic pages + injected maps for THIS rank's shard (page ids are global: rank*NP + i)
-    pages, scores, geos, rects_all = [], [], [], []
+    # synthetic pages + injected maps of THIS rank's shard (global page id = rank*NP + i)
+    pages, scores, geos = [], [], []
     for i in range(NP):
-        seed = 100 + rank * NP + i
+        seed = 200 + rank * NP + i
         pg, rects = synth.synth_page(seed, H, W)
         s, g = synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed)
-        pages.append(pg), scores.append(s), geos.append(g), rects_all.append(rects)
+        pages.append(pg), scores.append(s), geos.append(g)
     pages_dev = torch.from_numpy(np.stack(pages)).cuda()
     maps_dev = (torch.from_numpy(np.stack(scores)).cuda(), torch.from_numpy(np.stack(geos)).cuda())
-    orig_hw = (H, W)
 
     def step():
-        score, geo, boxes, nbox, counts = det.detect_device(pages_dev, maps_dev)
-        nb = nbox.cpu().numpy()
-        bx = boxes[:, : max(int(nb.max()), 1)].cpu().numpy()
-        return [det._host_tail(bx[n, : nb[n]], orig_hw) for n in range(NP)]
+        if pipe is not None:
+            return pipe.predict_batch(pages, pages_dev=pages_dev, _maps_override=maps_dev)
+        return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    out = None
     for _ in range(a.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -98,23 +111,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # final gather of decoded records (here: box arrays) to every rank, rank 0 keeps them
-        payload = np.concatenate([o.reshape(-1) for o in out]).astype(np.float32).view(np.uint8)
-        n_local = torch.tensor([payload.size], dtype=torch.int64, device="cuda")
-        sizes = [torch.zeros_like(n_local) for _ in range(world)]
-        dist.all_gather(sizes, n_local)
-        cap = int(max(int(s.item()) for s in sizes))
-        buf = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-        buf[: payload.size] = torch.from_numpy(payload.copy()).cuda()
-        allbuf = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(allbuf, buf)
+    # the path's one real exchange: decoded strings/boxes of every rank gathered (RCCL when world > 1)
+    records = gather_records([r for i, p in enumerate(out) for r in page_records(rank * NP + i, p)], torch.device("cuda", local))
 
     total_pages = NP * a.steps * world
-    value = total_pages / dt
-
+    words = [w for p in out for b in p.blocks for w in b.words]
+    n_crops = sum(1 for w in words if w.text is not None)
+    gflop_page = 2 * east_conv_macs(H, W) / 1e9
     res = {
         "metric": "manuscript pages/sec end-to-end (EAST+TRBA) at 1/2/4/8 MI355X; CER vs CPU ref",
-        "value": value,
+        "value": total_pages / dt,
         "unit": "pages/s",
         "n_gpus": world,
         "steps": a.steps,
@@ -126,20 +132,25 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16"}[a.precision],
         "data": "synthetic",
         "config": {
-            "workload": f"EAST detector only (BASELINE configs[1]): batch={NP} pages @ {W}x{H} per GPU, native network input "
-                        f"{H}x{W}, ResNet-50 EAST forward + quad decode + locality-aware NMS + box post-filters; "
-                        "decode/NMS on injected synthetic maps (random weights give unusable maps)",
+            "workload": (f"full EAST->crop->TRBA pipeline (BASELINE configs[3]): batch={NP} pages @ {W}x{H} per GPU, native network "
+                         f"input {H}x{W}; EAST forward + decode + LANMS + filters + reading order + device crop/ResizeAndPadA + "
+                         "TRBA 32x100 beam-8; decode/NMS on injected synthetic maps (random weights give unusable maps)")
+            if a.workload == "pipeline" else
+            (f"EAST detector only (BASELINE configs[1]): batch={NP} pages @ {W}x{H} per GPU, native network input {H}x{W}; "
+             "forward + decode + LANMS + filters; decode/NMS on injected synthetic maps"),
             "pages_per_step_per_gpu": NP,
             "page_hw": [H, W],
-            "gflop_per_page": 2 * east_conv_macs(H, W) / 1e9,
+            "gflop_per_page_east": gflop_page,
+            "gflop_per_crop_trba_cnn": 2 * trba_cnn_macs(32, 100) / 1e9,
+            "words_per_page": len(words) / NP,
+            "crops_per_page": n_crops / NP,
             "weights": "seeded synthetic (no checkpoint offline)",
-            "parallelism": f"pages sharded over {world} rank(s), no data-path collective",
+            "parallelism": f"pages sharded over {world} rank(s), no data-path collective; final all_gather of {len(records)} records",
         },
-        "boxes_per_page": float(np.mean([len(o) for o in out])),
     }
 
     if rank == 0 and not a.no_roofline:
-        # live HIP-event timing of every implicit-GEMM launch over a.steps instrumented steps
+        # live HIP-event timing of every implicit-GEMM launch (events on the launch stream = torch's current stream)
         ops.PROFILE = []
         for _ in range(a.steps):
             step()
@@ -147,25 +158,24 @@ def main():
         prof, ops.PROFILE = ops.PROFILE, None
         ms = np.array([e0.elapsed_time(e1) for e0, e1, _, _ in prof])
         fl = np.array([f for _, _, f, _ in prof])
-        launches = len(prof)
         tf = fl.sum() / (ms.sum() * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.precision]
         res["roofline"] = {
-            "kernel": "conv_igemm_kernel (all launches of one step, FLOP-weighted)",
+            "kernel": "conv_igemm_kernel (all implicit-GEMM launches of a step, FLOP-weighted)",
             "bound": "mfma",
             "achieved": tf,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": tf / peak,
             "traffic": None,
-            "launches_per_step": launches // a.steps,
+            "launches_per_step": len(prof) // a.steps,
             "avg_launch_ms": float(ms.mean()),
             "conv_ms_per_step": float(ms.sum() / a.steps),
             "alg_gflop_per_step": float(fl.sum() / a.steps / 1e9),
         }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(sd, pages, scores, geos, H, W)
+        res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out)
 
     if rank == 0:
         print(json.dumps(res))
@@ -173,23 +183,44 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, pages, scores, geos, H, W, budget_s=20.0):
-    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload; also the
+    CER of the GPU text against this CPU text on the sampled pages."""
     from oracle import east_model as oem
     from oracle import east_post as P
     from oracle import imgproc
     from oracle import lanms as L
+    from oracle import pipeline_glue as G
+    from oracle import trba_model as otm
 
     net = oem.EASTNet()
-    net.load_state_dict(sd)
+    net.load_state_dict(esd)
     net.eval()
+    tnet = otm.TRBANet(194, 256)
+    tnet.load_state_dict(tsd)
+    tnet.eval()
+    itos, _ = otm.load_charset(os.path.join(ROOT, "manuscript_ocr_amd", "recognizers", "_trba", "configs", "charset.txt"))
     L.lib()
     n, t0 = 0, time.perf_counter()
+    edits = chars = mism = 0
     with torch.no_grad():
-        for pg, s, g in zip(pages, scores, geos):
-            x = torch.from_numpy(imgproc.east_preprocess(pg, W, H))
-            net(x)
-            P.east_postprocess(s, g, (H, W), (W, H), L.locality_aware_nms)
+        for pi, (pg, s, g) in enumerate(zip(pages, scores, geos)):
+            net(torch.from_numpy(imgproc.east_preprocess(pg, W, H)))
+            quads = P.east_postprocess(s, g, (H, W), (W, H), L.locality_aware_nms)
+            if workload == "pipeline":
+                polys = [q[:8].reshape(4, 2).tolist() for q in quads]
+                order, kept, crops = G.order_and_crop(polys, pg, 5)
+                texts = []
+                for c0 in range(0, len(crops), 32):
+                    x = torch.from_numpy(np.stack([imgproc.trba_preprocess(c, 32, 100) for c in crops[c0:c0 + 32]]))
+                    lg, ids = tnet(x, max_len=25, mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
+                    texts += [r["text"] for r in otm.texts_and_confidences(lg, ids, itos, 0, 2, None)]
+                gw = [w for w in gpu_pages[pi].blocks[0].words]
+                gtexts = [gw[pos].text for pos in kept] if len(gw) == len(order) else []
+                mism += int(len(gw) != len(order))
+                for ref_t, hyp in zip(texts, gtexts):
+                    edits += _lev(ref_t, hyp or "")
+                    chars += max(len(ref_t), 1)
             n += 1
             if time.perf_counter() - t0 > budget_s:
                 break
@@ -199,9 +230,23 @@ def cpu_baseline(sd, pages, scores, geos, H, W, budget_s=20.0):
         "unit": "pages/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n} page(s) @ {W}x{H}: oracle torch-CPU fp32 EAST forward + C LANMS + NumPy filters on the same "
-                  f"synthetic pages/injected maps ({el:.1f} s)",
+        "sample": f"{n} page(s) @ {W}x{H} of the same synthetic workload: oracle torch-CPU fp32 EAST forward + C LANMS + NumPy "
+                  f"filters" + (" + reading order + crops + torch-CPU TRBA beam-8" if workload == "pipeline" else "") + f" ({el:.1f} s)",
+        "cer_gpu_vs_cpu": (edits / chars) if chars else None,
+        "box_count_mismatch_pages": mism,
     }
+
+
+def _lev(a, b):
+    if a == b:
+        return 0
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
 
 
 if __name__ == "__main__":

@@ -144,6 +144,12 @@ int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_
 int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                              float* logits_out, int32_t* ids_out, void* stream);
 
+/* Recognition confidence (recognizers/_trba/__init__.py:413-431): mean over the t_run generated positions of
+ * exp(log_softmax(logits)[id]).  logits [B][steps][V] f32, ids [B][steps] i32 (must be valid for t < trun[b]),
+ * trun_dev [B] i32 -> conf_out [B] f32 (0 when t_run == 0). */
+int msocr_seq_confidence(const float* logits, const int32_t* ids, const int32_t* trun_dev, int B, int V, int steps,
+                         float* conf_out, void* stream);
+
 /* Word crops -> recogniser canvases on the device: clamped AABB crop (Pipeline._extract_word_image,
  * _pipeline.py:204-221) + ResizeAndPadA (recognizers/_trba/data/transforms.py:85-120: aspect-preserving resize,
  * INTER_AREA if any axis shrinks else INTER_LINEAR, pasted at x=0 / vertically centred on a 255 canvas).

@@ -167,8 +167,7 @@ class Pipeline:
                 n0 += c
         if len(desc):
             canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-            logits, ids, trun = rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])
-            self._assign(all_words, rec._results(logits, ids, trun))
+            self._assign(all_words, rec._results(*rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])))
         return pages
 
     def process_batch(self, images: List[Union[str, np.ndarray, Image.Image]], recognize_text: bool = True, vis: bool = False,

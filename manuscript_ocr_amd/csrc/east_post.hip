@@ -193,33 +193,106 @@ template <typename K>
 __device__ __forceinline__ bool key_less(K a, K b) { return a < b || (b != b && a == a); }
 
 // ------------------------------------------------------------------------------------------ LANMS
-// workspace layout per page (all 8-byte aligned):
-//   order  int32[max_cand]     x0-sorted candidate indices, later score-sorted merged indices
-//   mpoly  double[max_cand*8]  merged polygons (phase 1)
-//   mscore double[max_cand]
-//   supp   int32[max_cand]     suppression flags (phase 2)
+// One workgroup (1024 threads) per page.
+//
+// Phase 1 of the reference (lanms.py:174-192) is a sequential scan: each x0-sorted candidate either merges
+// into the LAST merged polygon (weighted mean after vertex-order normalisation) or starts a new one.  It
+// is parallelised EXACTLY with a speculative segmented scan:
+//   A. every thread scans its own contiguous segment starting from an EMPTY state and records where it
+//      starts new polygons (spec_break) and its final open polygon (carry_spec);
+//   B. with the predecessor's carry as the true incoming state, a thread re-scans only until it starts a
+//      new polygon at a position where the speculative scan ALSO started one: from there both scans hold
+//      the identical state fresh(candidate) and see identical inputs, so the speculative tail is the true
+//      tail.  Carries are iterated to a fixed point (a run that spans several segments needs one round per
+//      segment; typical pages need two rounds);
+//   C. the true prefix is replayed once more to emit closed polygons into slots indexed by the polygon's
+//      LAST candidate (unique), replacing the speculative emissions of that prefix;
+//   D. the flagged slots are compacted in order.
+// Every floating-point operation is the reference's, in the reference's order, so results are bit-identical.
+//
+// workspace layout per page (8-byte aligned blocks):
+//   mpoly  f64[max_cand*8], mscore f64[max_cand]   compacted merged polygons (phase 1 output)
+//   spoly  f64[max_cand*8], sscore f64[max_cand]   staged slots (by last candidate)
+//   carry  f64[3][1024][11]                        spec / current / next carry states (poly, weight, score, valid)
+//   order  i32[max_cand], supp i32[max_cand], flag i32[max_cand], sbreak i32[max_cand]
+#define LANMS_T 1024
+#define CARRY_W 11
 static inline int64_t lanms_ws_per_page(int max_cand) {
-  return (int64_t)max_cand * (4 + 64 + 8 + 4) + 64;
+  return (int64_t)max_cand * (2 * (64 + 8) + 4 * 4) + (int64_t)3 * LANMS_T * CARRY_W * 8 + 64;
 }
 extern "C" int64_t msocr_lanms_workspace_bytes(int N, int max_cand) {
   if (N <= 0 || max_cand <= 0) return 0;
   return (lanms_ws_per_page(max_cand) + 63) / 64 * 64 * N;
 }
 
-__global__ __launch_bounds__(1024) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
-                                                           int max_cand, double thr, float* __restrict__ boxes_out,
-                                                           int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride) {
+struct MergeState {
+  double p[8], w, sc;
+  int valid;
+};
+__device__ __forceinline__ void st_load(MergeState& st, const double* c) {
+  for (int k = 0; k < 8; ++k) st.p[k] = c[k];
+  st.w = c[8];
+  st.sc = c[9];
+  st.valid = c[10] != 0.0;
+}
+__device__ __forceinline__ void st_store(const MergeState& st, double* c) {
+  for (int k = 0; k < 8; ++k) c[k] = st.p[k];
+  c[8] = st.w;
+  c[9] = st.sc;
+  c[10] = st.valid ? 1.0 : 0.0;
+}
+__device__ __forceinline__ bool st_same(const MergeState& st, const double* c) {
+  if ((c[10] != 0.0) != (st.valid != 0)) return false;
+  if (!st.valid) return true;
+  bool same = __double_as_longlong(st.w) == __double_as_longlong(c[8]) && __double_as_longlong(st.sc) == __double_as_longlong(c[9]);
+  for (int k = 0; k < 8; ++k) same = same && __double_as_longlong(st.p[k]) == __double_as_longlong(c[k]);
+  return same;
+}
+// one candidate of the reference loop body (lanms.py:174-192); returns true if it started a new polygon
+__device__ __forceinline__ bool merge_step(MergeState& st, const float* b, double thr, MergeState* closed) {
+  double poly[8];
+  for (int k = 0; k < 8; ++k) poly[k] = (double)b[k];
+  const double sc = (double)b[8];
+  if (st.valid && d_polygon_iou(poly, st.p) > thr) {
+    double al[8];
+    d_normalize_polygon(st.p, poly, al);
+    const double tw = st.w + sc;
+    for (int k = 0; k < 8; ++k) st.p[k] = (st.p[k] * st.w + al[k] * sc) / tw;
+    st.w = tw;
+    st.sc = st.sc > sc ? st.sc : sc;
+    return false;
+  }
+  if (closed) *closed = st;
+  for (int k = 0; k < 8; ++k) st.p[k] = poly[k];
+  st.w = sc;
+  st.sc = sc;
+  st.valid = 1;
+  return true;
+}
+
+__global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
+                                                              int max_cand, double thr, float* __restrict__ boxes_out,
+                                                              int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride) {
   const int pg = blockIdx.x;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x, nthr = LANMS_T;
   const float* cb = cand + (long)pg * max_cand * 9;
   const int n = counts[pg] & 0x7fffffff;
   char* w = ws + (long)pg * ws_stride;
   double* mpoly = reinterpret_cast<double*>(w);
   double* mscore = mpoly + (long)max_cand * 8;
-  int32_t* order = reinterpret_cast<int32_t*>(mscore + max_cand);
+  double* spoly = mscore + max_cand;
+  double* sscore = spoly + (long)max_cand * 8;
+  double* carry_spec = sscore + max_cand;
+  double* carry_cur = carry_spec + LANMS_T * CARRY_W;
+  double* carry_nxt = carry_cur + LANMS_T * CARRY_W;
+  int32_t* order = reinterpret_cast<int32_t*>(carry_nxt + LANMS_T * CARRY_W);
   int32_t* supp = order + max_cand;
+  int32_t* flag = supp + max_cand;
+  int32_t* sbreak = flag + max_cand;
   float* ob = boxes_out + (long)pg * max_cand * 9;
-  __shared__ int nm_s, nk_s, cur_alive;
+  __shared__ int nm_s, nk_s, cur_alive, any_changed;
+  __shared__ int scan_s[LANMS_T / 64];
+  __shared__ unsigned char ch_s[LANMS_T];
   __shared__ double cur_poly[8];
 
   if (n == 0) {
@@ -235,38 +308,131 @@ __global__ __launch_bounds__(1024) void east_lanms_kernel(const float* __restric
       rank += (key_less(kj, ki) || (!key_less(ki, kj) && j < i)) ? 1 : 0;
     }
     order[rank] = i;
+    flag[i] = 0;
+    sbreak[i] = 0;
   }
   __syncthreads();
-  // ---- phase 1: sequential weighted merge with the LAST merged polygon (lanms.py:174-192)
-  if (tid == 0) {
-    int nm = 0;
-    double last[8], lscore = 0.0, lw = 0.0;
-    for (int s = 0; s < n; ++s) {
-      const float* b = cb + (long)order[s] * 9;
-      double poly[8];
-      for (int k = 0; k < 8; ++k) poly[k] = (double)b[k];
-      const double sc = (double)b[8];
-      if (nm > 0 && d_polygon_iou(poly, last) > thr) {
-        double al[8];
-        d_normalize_polygon(last, poly, al);
-        const double tw = lw + sc;
-        for (int k = 0; k < 8; ++k) last[k] = (last[k] * lw + al[k] * sc) / tw;
-        lw = tw;
-        lscore = lscore > sc ? lscore : sc;
-        continue;
+
+  // ---- phase 1: speculative segmented scan -------------------------------------------------------------
+  int S = (n + 7) / 8;  // >= 8 candidates per segment
+  if (S > nthr) S = nthr;
+  const int L = (n + S - 1) / S;
+  S = (n + L - 1) / L;
+  const int seg0 = tid * L, seg1 = min(n, seg0 + L);
+  const bool active = tid < S;
+  // A. speculative scan from EMPTY
+  if (active) {
+    MergeState st;
+    st.valid = 0;
+    st.w = st.sc = 0.0;
+    for (int k = 0; k < 8; ++k) st.p[k] = 0.0;
+    for (int s = seg0; s < seg1; ++s) {
+      MergeState closed;
+      closed.valid = 0;
+      if (merge_step(st, cb + (long)order[s] * 9, thr, &closed)) {
+        sbreak[s] = 1;
+        if (closed.valid) {  // polygon that ended at candidate s-1
+          for (int k = 0; k < 8; ++k) spoly[(long)(s - 1) * 8 + k] = closed.p[k];
+          sscore[s - 1] = closed.sc;
+          flag[s - 1] = 1;
+        }
       }
-      if (nm > 0) {
-        for (int k = 0; k < 8; ++k) mpoly[(long)(nm - 1) * 8 + k] = last[k];
-        mscore[nm - 1] = lscore;
-      }
-      for (int k = 0; k < 8; ++k) last[k] = poly[k];
-      lscore = sc;
-      lw = sc;
-      nm++;
     }
-    for (int k = 0; k < 8; ++k) mpoly[(long)(nm - 1) * 8 + k] = last[k];
-    mscore[nm - 1] = lscore;
-    nm_s = nm;
+    st_store(st, carry_spec + tid * CARRY_W);
+    st_store(st, carry_cur + tid * CARRY_W);
+  }
+  if (tid == 0) any_changed = 0;
+  __syncthreads();
+  // B. fixed point of the carries (thread 0's carry is already true: its incoming state IS empty)
+  int in_dirty = active && tid > 0;  // my incoming carry has not been consumed yet
+  for (int round = 0; round < S; ++round) {
+    int changed = 0;
+    if (in_dirty) {
+      MergeState st;
+      st_load(st, carry_cur + (tid - 1) * CARRY_W);
+      bool resync = false;
+      for (int s = seg0; s < seg1; ++s) {
+        if (merge_step(st, cb + (long)order[s] * 9, thr, nullptr) && sbreak[s]) {
+          resync = true;
+          break;
+        }
+      }
+      if (resync) st_load(st, carry_spec + tid * CARRY_W);
+      changed = !st_same(st, carry_cur + tid * CARRY_W);
+      if (changed) st_store(st, carry_nxt + tid * CARRY_W);
+    }
+    ch_s[tid] = (unsigned char)changed;
+    if (changed) atomicOr(&any_changed, 1);
+    __syncthreads();  // every thread has read its predecessor's carry_cur and published `changed`
+    const int any = any_changed;
+    if (changed)
+      for (int k = 0; k < CARRY_W; ++k) carry_cur[tid * CARRY_W + k] = carry_nxt[tid * CARRY_W + k];
+    in_dirty = active && tid > 0 && ch_s[tid - 1];
+    __syncthreads();
+    if (tid == 0) any_changed = 0;
+    __syncthreads();
+    if (!any) break;
+  }
+  // C. replay the true prefix of every segment, emitting closed polygons into their slots
+  if (active) {
+    MergeState st;
+    if (tid == 0) {
+      st.valid = 0;
+      st.w = st.sc = 0.0;
+      for (int k = 0; k < 8; ++k) st.p[k] = 0.0;
+    } else {
+      st_load(st, carry_cur + (tid - 1) * CARRY_W);
+    }
+    bool resync = (tid == 0);  // segment 0's speculative scan is the true scan
+    for (int s = seg0; s < seg1 && !resync; ++s) {
+      MergeState closed;
+      closed.valid = 0;
+      const bool brk = merge_step(st, cb + (long)order[s] * 9, thr, &closed);
+      if (s > 0) {
+        if (brk && closed.valid) {
+          for (int k = 0; k < 8; ++k) spoly[(long)(s - 1) * 8 + k] = closed.p[k];
+          sscore[s - 1] = closed.sc;
+          flag[s - 1] = 1;
+        } else {
+          flag[s - 1] = 0;  // a speculative emission that the true scan does not make
+        }
+      }
+      if (brk && sbreak[s]) resync = true;
+    }
+    if (tid == S - 1) {  // the last open polygon of the page ends at candidate n-1
+      MergeState fin;
+      if (resync) st_load(fin, carry_spec + tid * CARRY_W); else fin = st;
+      for (int k = 0; k < 8; ++k) spoly[(long)(n - 1) * 8 + k] = fin.p[k];
+      sscore[n - 1] = fin.sc;
+      flag[n - 1] = 1;
+    }
+  }
+  __syncthreads();
+  // D. ordered compaction of the flagged slots
+  {
+    const int per = (n + nthr - 1) / nthr;
+    const int a0 = tid * per, a1 = min(n, a0 + per);
+    int cnt = 0;
+    for (int s = a0; s < a1; ++s) cnt += flag[s];
+    const int lane = tid & 63, wv = tid >> 6;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) scan_s[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wv; ++q) base += scan_s[q];
+    int pos = base + inc - cnt;
+    for (int s = a0; s < a1; ++s)
+      if (flag[s]) {
+        for (int k = 0; k < 8; ++k) mpoly[(long)pos * 8 + k] = spoly[(long)s * 8 + k];
+        mscore[pos] = sscore[s];
+        ++pos;
+      }
+    if (tid == nthr - 1) nm_s = base + inc;
   }
   __syncthreads();
   const int nm = nm_s;

@@ -632,3 +632,35 @@ extern "C" int msocr_attn_beam_finalize(const void* workspace, int B, int V, int
                logits_out, ids_out);
   return LAUNCH_OK();
 }
+
+// --------------------------------------------------------------------------------------------- confidence
+// TRBA.predict's confidence (recognizers/_trba/__init__.py:413-431): log_softmax over V of the returned logits,
+// exp of the chosen token's log-prob, mean over ALL t_run generated positions.  One wave per row.
+__global__ __launch_bounds__(64) void seq_confidence_kernel(const float* __restrict__ logits, const int32_t* __restrict__ ids,
+                                                             const int32_t* __restrict__ trun, int V, int steps,
+                                                             float* __restrict__ conf) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int tr = trun[b];
+  float acc = 0.f;
+  for (int t = 0; t < tr; ++t) {
+    const float* x = logits + ((long)b * steps + t) * V;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(x[v] - m);
+    s = wave_sum(s);
+    const int id = ids[(long)b * steps + t];
+    const float logp = (x[id] - m) - logf(s);
+    acc += expf(logp);
+  }
+  if (lane == 0) conf[b] = tr > 0 ? acc / (float)tr : 0.f;
+}
+
+extern "C" int msocr_seq_confidence(const float* logits, const int32_t* ids, const int32_t* trun_dev, int B, int V, int steps,
+                                    float* conf_out, void* stream) {
+  if (!logits || !ids || !trun_dev || !conf_out || B <= 0 || V <= 0 || steps <= 0) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(seq_confidence_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ids, trun_dev, V, steps, conf_out);
+  return LAUNCH_OK();
+}

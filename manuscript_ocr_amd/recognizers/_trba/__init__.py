@@ -7,7 +7,7 @@ decoder (greedy and beam) run on the MI355X through libmsocr.so; there is no CPU
 
 Extensions (keyword-only): precision="fp32"|"bf16" for the CNN (recurrent/attention stages are
 always exact f32), state_dict=... / config=... for in-memory weights (nothing can be downloaded
-offline), device_batch=256 rows per launch sequence.  Confidences reproduce the reference's
+offline), device_batch=2048 rows per launch sequence.  Confidences reproduce the reference's
 dependence on `batch_size` chunks (its decode loop stops per chunk, model.py:215,254).
 """
 import json
@@ -35,7 +35,7 @@ class TRBA:
         precision = kwargs.pop("precision", "fp32")
         state_dict = kwargs.pop("state_dict", None)
         config = kwargs.pop("config", None)
-        self.device_batch = int(kwargs.pop("device_batch", 256))
+        self.device_batch = int(kwargs.pop("device_batch", 2048))
         if kwargs:
             raise TypeError(f"Unexpected keyword argument(s): {', '.join(kwargs.keys())}")
         if weights_path is not None and model_path is not None:
@@ -135,15 +135,18 @@ class TRBA:
 
     # ------------------------------------------------------------------------------------- device path
     def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
-                           spans=None):
-        """canvases [N,img_h,img_w,3] u8 on device -> (logits [N,steps,V] f32, ids [N,steps] i32, t_run [N]) on host.
+                           spans=None, return_logits=False):
+        """canvases [N,img_h,img_w,3] u8 on device -> (ids [N,steps] i32, t_run [N] i32, conf [N] f32[, logits]) on host.
 
         `spans` = [(start, count), ...] groups of rows that the reference would have passed to ONE predict() call
         (one page each); inside a span rows are chunked by `batch_size` and every chunk stops at its own step
         (greedy: first step where every row emits EOS; beam: once every beam of every row is finished) — that run
-        length enters the confidences.  The device batches (`device_batch` rows) are independent of that chunking."""
+        length enters the confidences.  The device batches (`device_batch` rows) are independent of that chunking.
+        Confidences are reduced on the device (msocr_seq_confidence): only ids and one float per row cross PCIe."""
         if mode not in ("greedy", "beam"):
             raise ValueError(f"Unknown mode: {mode}")
+        from ... import _native as nat
+        from ... import ops
         N = canvases_dev.shape[0]
         spans = spans if spans is not None else [(0, N)]
         steps = self.max_length + 1 if mode == "greedy" else self.max_length
@@ -164,34 +167,38 @@ class TRBA:
                     c1 = min(c0 + batch_size, s0 + cnt)
                     hit = np.flatnonzero(np.all(ids_h[c0:c1] == self.eos_id, axis=0))
                     trun[c0:c1] = (hit[0] + 1) if len(hit) else steps
-            logits_h = np.concatenate([p[0].cpu().numpy() for p in parts])
-            return logits_h, ids_h, trun
-        fin_h = np.concatenate([p[1].cpu().numpy() for p in parts])
-        for s0, cnt in spans:
-            for c0 in range(s0, s0 + cnt, batch_size):
-                c1 = min(c0 + batch_size, s0 + cnt)
-                trun[c0:c1] = fin_h[c0:c1].max()
+        else:
+            fin_h = np.concatenate([p[1].cpu().numpy() for p in parts])
+            for s0, cnt in spans:
+                for c0 in range(s0, s0 + cnt, batch_size):
+                    c1 = min(c0 + batch_size, s0 + cnt)
+                    trun[c0:c1] = fin_h[c0:c1].max()
         trun_dev = torch.from_numpy(trun).to(self.device)
-        outs_l, outs_i = [], []
-        for k, s in enumerate(range(0, N, self.device_batch)):  # phase 3: back-track every row at its chunk's run length
+        ids_out, conf_out, logit_out = [], [], []
+        for k, s in enumerate(range(0, N, self.device_batch)):  # phase 3: back-track (beam) + confidence, per device batch
             B = min(self.device_batch, N - s)
-            lg, ids = self.model.beam_finalize(parts[k][0], B, steps, beam_size, trun_dev[s:s + B])
-            outs_l.append(lg.cpu().numpy()), outs_i.append(ids.cpu().numpy())
-        return np.concatenate(outs_l), np.concatenate(outs_i), trun
+            tr = trun_dev[s:s + B]
+            if mode == "greedy":
+                lg, ids = parts[k]
+            else:
+                lg, ids = self.model.beam_finalize(parts[k][0], B, steps, beam_size, tr)
+            conf = torch.empty((B,), dtype=torch.float32, device=self.device)
+            nat.check(nat.lib().msocr_seq_confidence(lg.data_ptr(), ids.data_ptr(), tr.data_ptr(), B, self.model.V, steps, conf.data_ptr(),
+                                                     ops._stream()), "seq_confidence")
+            ids_out.append(ids), conf_out.append(conf)
+            if return_logits:
+                logit_out.append(lg.cpu().numpy())
+            parts[k] = None
+        ids_h = torch.cat(ids_out).cpu().numpy()
+        conf_h = torch.cat(conf_out).cpu().numpy()
+        if return_logits:
+            return ids_h, trun, conf_h, np.concatenate(logit_out)
+        return ids_h, trun, conf_h
 
-    def _results(self, logits, ids, trun) -> List[Dict[str, Any]]:
-        """__init__.py:413-432: log_softmax, decode_tokens, confidence = mean over ALL generated positions."""
-        res = []
-        for j in range(len(ids)):
-            t = int(trun[j])
-            row = ids[j, :t]
-            x = logits[j, :t].astype(np.float32)
-            m = x.max(axis=-1, keepdims=True)
-            logp = x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=np.float32))
-            text = decode_tokens(row, self.itos, self.pad_id, self.eos_id, self.blank_id)
-            conf = float(np.exp(logp[np.arange(t), row]).mean(dtype=np.float32)) if t > 0 else 0.0
-            res.append({"text": text, "confidence": conf})
-        return res
+    def _results(self, ids, trun, conf) -> List[Dict[str, Any]]:
+        """__init__.py:415-432: decode_tokens over the t_run generated ids; confidence computed on the device."""
+        return [{"text": decode_tokens(ids[j, : int(trun[j])], self.itos, self.pad_id, self.eos_id, self.blank_id),
+                 "confidence": float(conf[j])} for j in range(len(ids))]
 
     # ------------------------------------------------------------------------------------- API
     def predict(self, images, batch_size: int = 32, mode: str = "beam", beam_size: int = 8, temperature: float = 1.7,
@@ -203,5 +210,4 @@ class TRBA:
         if not images_list:
             return []
         canv = torch.from_numpy(self._canvases(images_list)).to(self.device, non_blocking=True)
-        logits, ids, trun = self.recognize_canvases(canv, batch_size, mode, beam_size, temperature, alpha)
-        return self._results(logits, ids, trun)
+        return self._results(*self.recognize_canvases(canv, batch_size, mode, beam_size, temperature, alpha))

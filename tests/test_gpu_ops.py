@@ -225,3 +225,31 @@ def test_decode_lanms_pipeline_vs_oracle(ops):
         exp = L.locality_aware_nms(dec, 0.2)
         assert nbox[n] == len(exp)
         assert np.array_equal(boxes[n, :nbox[n]].cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed,n_base,max_run", [(0, 1, 3000), (1, 5, 900), (2, 60, 200), (3, 400, 12), (4, 3, 2), (5, 1, 1), (6, 2000, 3)])
+def test_lanms_speculative_scan_long_and_short_runs(ops, seed, n_base, max_run):
+    """Merge runs from 1 to 3000 candidates (far longer than one thread's segment, forcing multi-round carry
+    fix-ups) and pages with almost no merging: HIP LANMS == oracle, bit for bit."""
+    from oracle import lanms as L
+    rng = np.random.default_rng(seed)
+    rows = []
+    x = 10.0
+    for _ in range(n_base):
+        w, h = rng.uniform(40, 200), rng.uniform(12, 40)
+        y = rng.uniform(10, 1500)
+        base = np.array([x, y, x + w, y, x + w, y + h, x, y + h])
+        for _ in range(int(rng.integers(1, max_run + 1))):
+            q = base + rng.normal(0, 0.4, 8)
+            rows.append(np.concatenate([q, [rng.uniform(0.05, 1.0)]]))
+        x += rng.uniform(0.3, 1.2) * w  # neighbours overlap in x, sometimes in y
+    inp = np.asarray(rows, dtype=np.float32)
+    inp = inp[rng.permutation(len(inp))]
+    exp = L.locality_aware_nms(inp, 0.2)  # x0 ties (if any) resolve by index in the oracle and on the device alike
+    mc = max(64, len(inp))
+    cand = torch.zeros(1, mc, 9, dtype=torch.float32, device="cuda")
+    cand[0, :len(inp)] = torch.from_numpy(inp).cuda()
+    boxes, nbox = ops.east_lanms(cand, torch.tensor([len(inp)], dtype=torch.int32, device="cuda"), 0.2)
+    nb = int(nbox.cpu()[0])
+    assert nb == len(exp)
+    assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
