@@ -149,6 +149,9 @@ def main():
         },
     }
 
+    if pipe is not None:
+        res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}
+        res["east_stage_s_last_step"] = {k: round(v, 4) for k, v in det.last_profile.items()}
     if rank == 0 and not a.no_roofline:
         # live HIP-event timing of every implicit-GEMM launch (events on the launch stream = torch's current stream)
         ops.PROFILE = []

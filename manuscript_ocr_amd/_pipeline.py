@@ -50,13 +50,10 @@ class Pipeline:
         words, crops = [], []
         for block in page.blocks:
             boxes = [_word_aabb(w)[0] for w in block.words]
-            new_order = []
-            for bx in sort_boxes_reading_order_with_resolutions(boxes):
-                for w, wb in zip(block.words, boxes):  # first equal word wins, as the reference's tuple comparison
-                    if wb == bx:
-                        new_order.append(w)
-                        break
-            block.words = new_order
+            first = {}
+            for k, bx in enumerate(boxes):  # first equal word wins, as the reference's tuple comparison (:113-121)
+                first.setdefault(tuple(int(v) for v in bx), k)
+            block.words = [block.words[first[tuple(int(v) for v in bx)]] for bx in sort_boxes_reading_order_with_resolutions(boxes)]
             for word in block.words:
                 (x0, y0, x1, y1), poly = _word_aabb(word)
                 if (x1 - x0) >= self.min_text_size and (y1 - y0) >= self.min_text_size:
@@ -128,33 +125,46 @@ class Pipeline:
         import torch
 
         from . import ops
+        tm = {}
+        t0 = time.perf_counter()
         arrays = [read_image(im) for im in images]
         if pages_dev is None:
             pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(self.detector.device)
         results = self.detector.predict_batch(arrays, profile=profile, _pages_dev=pages_dev, _maps_override=_maps_override)
         pages = [self._page_of(r) for r in results]
+        tm["detect"] = time.perf_counter() - t0
+        self.last_profile = tm
         if not recognize_text:
             return pages
+        t0 = time.perf_counter()
         rec = self.recognizer
         all_words, boxes, page_ids, spans = [], [], [], []
         for pi, page in enumerate(pages):
             n0 = len(all_words)
             for block in page.blocks:
-                aabbs = [_word_aabb(w)[0] for w in block.words]
-                new_order = []
-                for bx in sort_boxes_reading_order_with_resolutions(aabbs):
-                    for w, wb in zip(block.words, aabbs):
-                        if wb == bx:
-                            new_order.append(w)
-                            break
-                block.words = new_order
-                for word in block.words:
-                    (x0, y0, x1, y1), _ = _word_aabb(word)
+                if not block.words:
+                    continue
+                # AABBs of all words at once: np.array(polygon, int32) truncates toward zero (_pipeline.py:106)
+                polys = np.array([w.polygon for w in block.words], dtype=np.float64).astype(np.int32)
+                mins, maxs = polys.min(axis=1), polys.max(axis=1)
+                aabbs = [(a[0], a[1], b[0], b[1]) for a, b in zip(mins, maxs)]
+                first = {}
+                for k, bx in enumerate(aabbs):  # "first equal word wins" of the reference's O(n^2) re-match (:113-121)
+                    first.setdefault(tuple(int(v) for v in bx), k)
+                order = [first[tuple(int(v) for v in bx)] for bx in sort_boxes_reading_order_with_resolutions(aabbs)]
+                old_words = block.words
+                block.words = [old_words[k] for k in order]
+                for k in order:
+                    x0, y0, x1, y1 = aabbs[k]
                     if (x1 - x0) >= self.min_text_size and (y1 - y0) >= self.min_text_size:
-                        all_words.append(word), boxes.append((x0, y0, x1, y1)), page_ids.append(pi)
+                        all_words.append(old_words[k])
+                        boxes.append((x0, y0, x1, y1))
+                        page_ids.append(pi)
             spans.append([n0, len(all_words) - n0])
+        tm["order"] = time.perf_counter() - t0
         if not boxes:
             return pages
+        t0 = time.perf_counter()
         H, W = arrays[0].shape[:2]
         desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
         if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
@@ -167,7 +177,15 @@ class Pipeline:
                 n0 += c
         if len(desc):
             canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-            self._assign(all_words, rec._results(*rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])))
+            tm["crop"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            out = rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])
+            tm["recognize"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            self._assign(all_words, rec._results(*out))
+            tm["assign"] = time.perf_counter() - t0
+        if profile:
+            print("Pipeline.predict_batch stages (s):", {k: round(v, 4) for k, v in tm.items()})
         return pages
 
     def process_batch(self, images: List[Union[str, np.ndarray, Image.Image]], recognize_text: bool = True, vis: bool = False,

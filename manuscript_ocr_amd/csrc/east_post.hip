@@ -8,6 +8,7 @@
 // One workgroup per page; every kernel has a bounded trip count (no spinning).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msocr.h"
 
@@ -124,14 +125,16 @@ __device__ int d_clip_polygon(const double* subject, int n, const double* A, con
     const bool curr_in = (B[0] - A[0]) * (curr[1] - A[1]) - (B[1] - A[1]) * (curr[0] - A[0]) >= 0;
     const bool prev_in = (B[0] - A[0]) * (prev[1] - A[1]) - (B[1] - A[1]) * (prev[0] - A[0]) >= 0;
     if (curr_in) {
-      if (!prev_in) {
+      if (!prev_in && count < MAXV) {
         d_compute_intersection(prev, curr, A, B, out + 2 * count);
         count++;
       }
-      out[2 * count] = curr[0];
-      out[2 * count + 1] = curr[1];
-      count++;
-    } else if (prev_in) {
+      if (count < MAXV) {
+        out[2 * count] = curr[0];
+        out[2 * count + 1] = curr[1];
+        count++;
+      }
+    } else if (prev_in && count < MAXV) {
       d_compute_intersection(prev, curr, A, B, out + 2 * count);
       count++;
     }
@@ -157,6 +160,36 @@ __device__ double d_polygon_iou(const double* poly1, const double* poly2) {  // 
   const double union_area = area1 + area2 - inter_area;
   if (union_area <= 0) return 0.0;
   return inter_area / union_area;
+}
+
+// Exact shortcut for far-apart quads: when the clip polygon (poly2) is strictly convex and the two axis-aligned
+// bounding boxes are separated by a margin far above rounding error, Sutherland-Hodgman returns an empty
+// polygon (every surviving vertex would have to lie within rounding distance of BOTH hulls), so
+// inter_area = 0 and the reference's IoU is exactly 0.0 (or 0.0 through its union<=0 guard).  Non-convex or
+// self-intersecting clip quads, whose half-plane intersection can be unbounded, always take the full path.
+__device__ __forceinline__ bool d_surely_disjoint(const double* p1, const double* p2) {
+  double s0 = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double ax = p2[2 * ((i + 1) & 3)] - p2[2 * i], ay = p2[2 * ((i + 1) & 3) + 1] - p2[2 * i + 1];
+    const double bx = p2[2 * ((i + 2) & 3)] - p2[2 * ((i + 1) & 3)], by = p2[2 * ((i + 2) & 3) + 1] - p2[2 * ((i + 1) & 3) + 1];
+    const double c = ax * by - ay * bx;
+    if (!(fabs(c) > 1e-9)) return false;           // degenerate turn (or NaN): not provably convex
+    if (i == 0) s0 = c; else if ((c > 0) != (s0 > 0)) return false;
+  }
+  double l1 = p1[0], r1 = p1[0], t1 = p1[1], b1 = p1[1], l2 = p2[0], r2 = p2[0], t2 = p2[1], b2 = p2[1];
+  for (int i = 1; i < 4; ++i) {
+    l1 = fmin(l1, p1[2 * i]); r1 = fmax(r1, p1[2 * i]); t1 = fmin(t1, p1[2 * i + 1]); b1 = fmax(b1, p1[2 * i + 1]);
+    l2 = fmin(l2, p2[2 * i]); r2 = fmax(r2, p2[2 * i]); t2 = fmin(t2, p2[2 * i + 1]); b2 = fmax(b2, p2[2 * i + 1]);
+  }
+  const double ext = fmax(fmax(fabs(l1), fabs(r1)), fmax(fmax(fabs(t1), fabs(b1)), fmax(fmax(fabs(l2), fabs(r2)), fmax(fabs(t2), fabs(b2)))));
+  const double margin = 1e-6 * (1.0 + ext);
+  if (!(ext < 1e12)) return false;                  // inf / NaN coordinates: full path
+  return (l1 > r2 + margin) || (l2 > r1 + margin) || (t1 > b2 + margin) || (t2 > b1 + margin);
+}
+__device__ int g_lanms_shortcut = 1;
+__device__ __forceinline__ double d_polygon_iou_q(const double* poly1, const double* poly2) {
+  if (g_lanms_shortcut && d_surely_disjoint(poly1, poly2)) return 0.0;
+  return d_polygon_iou(poly1, poly2);
 }
 
 __device__ void d_normalize_polygon(const double* ref, const double* poly, double* out) {  // :99-130
@@ -253,7 +286,7 @@ __device__ __forceinline__ bool merge_step(MergeState& st, const float* b, doubl
   double poly[8];
   for (int k = 0; k < 8; ++k) poly[k] = (double)b[k];
   const double sc = (double)b[8];
-  if (st.valid && d_polygon_iou(poly, st.p) > thr) {
+  if (st.valid && d_polygon_iou_q(poly, st.p) > thr) {
     double al[8];
     d_normalize_polygon(st.p, poly, al);
     const double tw = st.w + sc;
@@ -322,13 +355,9 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   const bool active = tid < S;
   // A. speculative scan from EMPTY
   if (active) {
-    MergeState st;
-    st.valid = 0;
-    st.w = st.sc = 0.0;
-    for (int k = 0; k < 8; ++k) st.p[k] = 0.0;
+    MergeState st = {};
     for (int s = seg0; s < seg1; ++s) {
-      MergeState closed;
-      closed.valid = 0;
+      MergeState closed = {};
       if (merge_step(st, cb + (long)order[s] * 9, thr, &closed)) {
         sbreak[s] = 1;
         if (closed.valid) {  // polygon that ended at candidate s-1
@@ -348,7 +377,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   for (int round = 0; round < S; ++round) {
     int changed = 0;
     if (in_dirty) {
-      MergeState st;
+      MergeState st = {};
       st_load(st, carry_cur + (tid - 1) * CARRY_W);
       bool resync = false;
       for (int s = seg0; s < seg1; ++s) {
@@ -375,18 +404,11 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   }
   // C. replay the true prefix of every segment, emitting closed polygons into their slots
   if (active) {
-    MergeState st;
-    if (tid == 0) {
-      st.valid = 0;
-      st.w = st.sc = 0.0;
-      for (int k = 0; k < 8; ++k) st.p[k] = 0.0;
-    } else {
-      st_load(st, carry_cur + (tid - 1) * CARRY_W);
-    }
+    MergeState st = {};
+    if (tid > 0) st_load(st, carry_cur + (tid - 1) * CARRY_W);
     bool resync = (tid == 0);  // segment 0's speculative scan is the true scan
     for (int s = seg0; s < seg1 && !resync; ++s) {
-      MergeState closed;
-      closed.valid = 0;
+      MergeState closed = {};
       const bool brk = merge_step(st, cb + (long)order[s] * 9, thr, &closed);
       if (s > 0) {
         if (brk && closed.valid) {
@@ -400,8 +422,8 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
       if (brk && sbreak[s]) resync = true;
     }
     if (tid == S - 1) {  // the last open polygon of the page ends at candidate n-1
-      MergeState fin;
-      if (resync) st_load(fin, carry_spec + tid * CARRY_W); else fin = st;
+      MergeState fin = st;
+      if (resync) st_load(fin, carry_spec + tid * CARRY_W);
       for (int k = 0; k < 8; ++k) spoly[(long)(n - 1) * 8 + k] = fin.p[k];
       sscore[n - 1] = fin.sc;
       flag[n - 1] = 1;
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
       for (int j = i + 1 + tid; j < nm; j += nthr) {
         const int idj = order[j];
         if (supp[idj]) continue;
-        if (d_polygon_iou(a, mpoly + (long)idj * 8) > thr) supp[idj] = 1;
+        if (d_polygon_iou_q(a, mpoly + (long)idj * 8) > thr) supp[idj] = 1;
       }
     }
     __syncthreads();
@@ -481,6 +503,15 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
   if (!cand || !counts || !boxes_out || !nbox_out || !workspace || N <= 0 || max_cand <= 0) return MSOCR_E_ARG;
   if ((uintptr_t)workspace & 7) return MSOCR_E_ARG;
   const long stride = (lanms_ws_per_page(max_cand) + 63) / 64 * 64;
+  {
+    const char* e = getenv("MSOCR_LANMS_SHORTCUT");
+    const int v = (e && e[0] == '0') ? 0 : 1;
+    static int cur = -1;
+    if (v != cur) {
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_lanms_shortcut), &v, sizeof(int)) != hipSuccess) return MSOCR_E_LAUNCH;
+      cur = v;
+    }
+  }
   MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
                      (char*)workspace, stride);
   return LAUNCH_OK();

@@ -149,6 +149,7 @@ class EAST:
         pages = _pages_dev if _pages_dev is not None else \
             torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
         score, geo, boxes, nbox, counts = self.detect_device(pages, _maps_override)
+        t_launch = time.time() - t0
         nbox_h = nbox.cpu().numpy()
         counts_h = counts.cpu().numpy()
         if np.any(counts_h < 0):
@@ -157,6 +158,7 @@ class EAST:
         if profile:
             print(f"  Model inference + decode + NMS (device): {time.time() - t0:.3f}s")
             print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
+        t_dev = time.time() - t0
         results = []
         for n, img in enumerate(imgs):
             quads = self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
@@ -170,6 +172,7 @@ class EAST:
                 "score_map": score[n].cpu().numpy() if return_maps else None,
                 "geo_map": geo[n].permute(2, 0, 1).contiguous().cpu().numpy() if return_maps else None,
             })
+        self.last_profile = {"launch": t_launch, "device_done": t_dev, "total": time.time() - t0}
         return results
 
     def predict(self, img_or_path: Union[str, Path, np.ndarray], vis: bool = False, profile: bool = False,
