@@ -8,6 +8,7 @@
 // One workgroup per page; every kernel has a bounded trip count (no spinning).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "msocr.h"
@@ -258,6 +259,84 @@ extern "C" int64_t msocr_lanms_workspace_bytes(int N, int max_cand) {
   return (lanms_ws_per_page(max_cand) + 63) / 64 * 64 * N;
 }
 
+// Order-preserving integer images of the sort keys: ascending float order, -0 == +0, every NaN last; the original
+// index in the low bits makes the order strict and the sort stable (np.argsort's default is unstable: ties are
+// implementation-defined in the reference).  rank_i = #{j : K_j < K_i} is then ONE unsigned compare per pair.
+__device__ __forceinline__ uint32_t sortable_f32(float x) {
+  if (x != x) return 0xffffffffu;
+  x = x + 0.0f;  // -0 -> +0
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long sortable_f64(double x) {
+  if (x != x) return 0xffffffffffffffffull;
+  x = x + 0.0;
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+#define RS_TILE 2048
+#define RS_Q 8
+// x0 sort of every page's candidates, spread over the whole chip: grid (chunks, pages), each workgroup ranks
+// 256*RS_Q candidates of one page against all n (keys staged through LDS as 64-bit (key, index) words).
+__global__ __launch_bounds__(256) void lanms_rank_x0_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
+                                                             int max_cand, char* __restrict__ ws, long ws_stride, long order_off) {
+  const int pg = blockIdx.y, tid = threadIdx.x;
+  const int n = counts[pg] & 0x7fffffff;
+  const int i0 = blockIdx.x * 256 * RS_Q;
+  if (i0 >= n) return;
+  const float* cb = cand + (long)pg * max_cand * 9;
+  int32_t* order = reinterpret_cast<int32_t*>(ws + (long)pg * ws_stride + order_off);
+  __shared__ unsigned long long tile[RS_TILE];
+  unsigned long long ki[RS_Q];
+  int rank[RS_Q];
+#pragma unroll
+  for (int q = 0; q < RS_Q; ++q) {
+    const int i = i0 + q * 256 + tid;
+    ki[q] = i < n ? (((unsigned long long)sortable_f32(cb[(long)i * 9]) << 32) | (unsigned)i) : 0ull;
+    rank[q] = 0;
+  }
+  for (int j0 = 0; j0 < n; j0 += RS_TILE) {
+    const int jn = min(RS_TILE, n - j0);
+    __syncthreads();
+    for (int j = tid; j < jn; j += 256) tile[j] = ((unsigned long long)sortable_f32(cb[(long)(j0 + j) * 9]) << 32) | (unsigned)(j0 + j);
+    __syncthreads();
+    for (int j = 0; j < jn; ++j) {
+      const unsigned long long kj = tile[j];
+#pragma unroll
+      for (int q = 0; q < RS_Q; ++q) rank[q] += kj < ki[q] ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RS_Q; ++q) {
+    const int i = i0 + q * 256 + tid;
+    if (i < n) order[rank[q]] = i;
+  }
+}
+
+// in-workgroup stable rank sort of nm f64 keys (descending score = ascending -score), nm is a few thousand at most
+__device__ __forceinline__ void block_rank_sort_neg_f64(int n, const double* __restrict__ score, int32_t* __restrict__ order,
+                                                        unsigned long long* tile /* LDS [RS_TILE] */) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i0 = 0; i0 < n; i0 += nthr) {
+    const int i = i0 + tid;
+    const unsigned long long ki = i < n ? sortable_f64(-score[i]) : 0ull;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += RS_TILE) {
+      const int jn = min(RS_TILE, n - j0);
+      __syncthreads();
+      for (int j = tid; j < jn; j += nthr) tile[j] = sortable_f64(-score[j0 + j]);
+      __syncthreads();
+      for (int j = 0; j < jn; ++j) {
+        const unsigned long long kj = tile[j];
+        rank += (kj < ki || (kj == ki && j0 + j < i)) ? 1 : 0;
+      }
+    }
+    if (i < n) order[rank] = i;
+  }
+  __syncthreads();
+}
+
 struct MergeState {
   double p[8], w, sc;
   int valid;
@@ -305,9 +384,11 @@ __device__ __forceinline__ bool merge_step(MergeState& st, const float* b, doubl
 
 __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
                                                               int max_cand, double thr, float* __restrict__ boxes_out,
-                                                              int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride) {
+                                                              int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride, long long* dbg) {
   const int pg = blockIdx.x;
   const int tid = threadIdx.x, nthr = LANMS_T;
+#define DBG_STAMP(k) do { if (dbg && tid == 0) dbg[pg * 8 + (k)] = wall_clock64(); } while (0)
+  DBG_STAMP(0);
   const float* cb = cand + (long)pg * max_cand * 9;
   const int n = counts[pg] & 0x7fffffff;
   char* w = ws + (long)pg * ws_stride;
@@ -332,20 +413,14 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
     if (tid == 0) nbox_out[pg] = 0;
     return;
   }
-  // ---- sort by x0 (f32 key), stable: rank = #{j : key_j < key_i or (tie and j < i)}  (lanms.py:166-168)
+  // ---- `order` already holds the stable argsort by x0 (lanms.py:166-168), computed by lanms_rank_x0_kernel
+  __shared__ unsigned long long rs_tile[RS_TILE];
   for (int i = tid; i < n; i += nthr) {
-    const float ki = cb[(long)i * 9];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const float kj = cb[(long)j * 9];
-      rank += (key_less(kj, ki) || (!key_less(ki, kj) && j < i)) ? 1 : 0;
-    }
-    order[rank] = i;
     flag[i] = 0;
     sbreak[i] = 0;
   }
   __syncthreads();
-
+  DBG_STAMP(1);
   // ---- phase 1: speculative segmented scan -------------------------------------------------------------
   int S = (n + 7) / 8;  // >= 8 candidates per segment
   if (S > nthr) S = nthr;
@@ -372,6 +447,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   }
   if (tid == 0) any_changed = 0;
   __syncthreads();
+  DBG_STAMP(2);
   // B. fixed point of the carries (thread 0's carry is already true: its incoming state IS empty)
   int in_dirty = active && tid > 0;  // my incoming carry has not been consumed yet
   for (int round = 0; round < S; ++round) {
@@ -402,6 +478,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
     __syncthreads();
     if (!any) break;
   }
+  DBG_STAMP(3);
   // C. replay the true prefix of every segment, emitting closed polygons into their slots
   if (active) {
     MergeState st = {};
@@ -430,6 +507,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
     }
   }
   __syncthreads();
+  DBG_STAMP(4);
   // D. ordered compaction of the flagged slots
   {
     const int per = (n + nthr - 1) / nthr;
@@ -458,44 +536,84 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   }
   __syncthreads();
   const int nm = nm_s;
+  DBG_STAMP(5);
   // ---- phase 2: order = argsort(-score) (stable), greedy suppression (lanms.py:133-153)
-  for (int i = tid; i < nm; i += nthr) {
-    const double ki = -mscore[i];
-    int rank = 0;
-    for (int j = 0; j < nm; ++j) {
-      const double kj = -mscore[j];
-      rank += (key_less(kj, ki) || (!key_less(ki, kj) && j < i)) ? 1 : 0;
-    }
-    order[rank] = i;
-    supp[i] = 0;
-  }
-  if (tid == 0) nk_s = 0;
+  block_rank_sort_neg_f64(nm, mscore, order, rs_tile);
+  for (int i = tid; i < nm; i += nthr) supp[i] = 0;
   __syncthreads();
-  for (int i = 0; i < nm; ++i) {
-    const int idx = order[i];
-    if (tid == 0) {
-      cur_alive = supp[idx] == 0;
-      if (cur_alive) {
-        for (int k = 0; k < 8; ++k) cur_poly[k] = mpoly[(long)idx * 8 + k];
-        float* o = ob + (long)nk_s * 9;
-        for (int k = 0; k < 8; ++k) o[k] = (float)cur_poly[k];
-        o[8] = (float)mscore[idx];
-        nk_s++;
+  int nk = 0;  // kept count (every thread tracks it; the owner of a kept polygon writes its row)
+  constexpr int NQ = 4;
+  if (nm <= NQ * LANMS_T) {
+    // fast path: sorted position j = tid + q*1024 lives in thread tid's registers (polygon + suppressed flag); per
+    // iteration the owner broadcasts polygon i through LDS (double-buffered: one barrier per iteration).
+    __shared__ double bc_poly[2][8];
+    __shared__ int bc_alive[2];
+    double mp[NQ][8];
+    int ms_idx[NQ];
+    bool sup[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int j = tid + q * LANMS_T;
+      sup[q] = true;
+      ms_idx[q] = 0;
+      if (j < nm) {
+        ms_idx[q] = order[j];
+        sup[q] = false;
+        for (int k = 0; k < 8; ++k) mp[q][k] = mpoly[(long)ms_idx[q] * 8 + k];
+      } else {
+        for (int k = 0; k < 8; ++k) mp[q][k] = 0.0;
       }
     }
-    __syncthreads();
-    if (cur_alive) {
+    for (int i = 0; i < nm; ++i) {
+      const int buf = i & 1, own = i % LANMS_T, oq = i / LANMS_T;
+      if (tid == own) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q == oq) {
+            bc_alive[buf] = sup[q] ? 0 : 1;
+            if (!sup[q]) {
+              for (int k = 0; k < 8; ++k) bc_poly[buf][k] = mp[q][k];
+              float* o = ob + (long)nk * 9;
+              for (int k = 0; k < 8; ++k) o[k] = (float)mp[q][k];
+              o[8] = (float)mscore[ms_idx[q]];
+            }
+          }
+      }
+      __syncthreads();
+      if (!bc_alive[buf]) continue;
+      ++nk;
       double a[8];
-      for (int k = 0; k < 8; ++k) a[k] = cur_poly[k];
+      for (int k = 0; k < 8; ++k) a[k] = bc_poly[buf][k];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int j = tid + q * LANMS_T;
+        if (j > i && j < nm && !sup[q] && d_polygon_iou_q(a, mp[q]) > thr) sup[q] = true;
+      }
+    }
+  } else {
+    for (int i = 0; i < nm; ++i) {
+      const int idx = order[i];
+      if (supp[idx]) continue;  // uniform: written before the barrier that ended an earlier iteration
+      double a[8];
+      for (int k = 0; k < 8; ++k) a[k] = mpoly[(long)idx * 8 + k];
+      if (tid == 0) {
+        float* o = ob + (long)nk * 9;
+        for (int k = 0; k < 8; ++k) o[k] = (float)a[k];
+        o[8] = (float)mscore[idx];
+      }
+      ++nk;
       for (int j = i + 1 + tid; j < nm; j += nthr) {
         const int idj = order[j];
         if (supp[idj]) continue;
         if (d_polygon_iou_q(a, mpoly + (long)idj * 8) > thr) supp[idj] = 1;
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
+  if (tid == 0) nk_s = nk;
   if (tid == 0) nbox_out[pg] = nk_s;
+  DBG_STAMP(6);
+  if (dbg && tid == 0) dbg[pg * 8 + 7] = ((long long)n << 32) | (unsigned)nm;
 }
 
 extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N, int max_cand, double iou_thr, float* boxes_out,
@@ -512,7 +630,31 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
       cur = v;
     }
   }
-  MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
-                     (char*)workspace, stride);
-  return LAUNCH_OK();
+  {
+    const long order_off = ((long)max_cand * (2 * (64 + 8)) + (long)3 * LANMS_T * CARRY_W * 8);
+    const int chunks = (max_cand + 256 * RS_Q - 1) / (256 * RS_Q);
+    MSOCR_LAUNCH(lanms_rank_x0_kernel, dim3(chunks, N), dim3(256), 0, (hipStream_t)stream, cand, counts, max_cand, (char*)workspace, stride,
+                 order_off);
+    if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+  }
+  long long* dbg = nullptr;
+  const bool want_dbg = getenv("MSOCR_LANMS_DEBUG") != nullptr;  // diagnostic only: synchronises and prints phase times
+  if (want_dbg && hipMalloc(&dbg, sizeof(long long) * 8 * N) != hipSuccess) dbg = nullptr;
+  MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(LANMS_T), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
+                     (char*)workspace, stride, dbg);
+  const int rc = LAUNCH_OK();
+  if (dbg) {
+    long long* h = (long long*)malloc(sizeof(long long) * 8 * N);
+    hipStreamSynchronize((hipStream_t)stream);
+    hipMemcpy(h, dbg, sizeof(long long) * 8 * N, hipMemcpyDeviceToHost);
+    for (int p = 0; p < N && p < 2; ++p) {
+      const long long* t = h + p * 8;
+      fprintf(stderr, "[lanms dbg] page %d n=%lld nm=%lld  us: sort %.0f specA %.0f fixB %.0f replayC %.0f compactD %.0f nms %.0f\n", p,
+              t[7] >> 32, t[7] & 0xffffffff, (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0, (t[4] - t[3]) / 100.0,
+              (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0);
+    }
+    free(h);
+    hipFree(dbg);
+  }
+  return rc;
 }
