@@ -163,6 +163,16 @@ def main():
         fl = np.array([f for _, _, f, _ in prof])
         tf = fl.sum() / (ms.sum() * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.precision]
+        if os.environ.get("MSOCR_DUMP_CONV"):
+            agg = {}
+            for (e0, e1, f, tag), m in zip(prof, ms):
+                a_ = agg.setdefault(tag, [0, 0.0, 0.0])
+                a_[0] += 1
+                a_[1] += m
+                a_[2] += f
+            with open(os.environ["MSOCR_DUMP_CONV"], "w") as fh:
+                for tag, (cnt, m, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
         res["roofline"] = {
             "kernel": "conv_igemm_kernel (all implicit-GEMM launches of a step, FLOP-weighted)",
             "bound": "mfma",

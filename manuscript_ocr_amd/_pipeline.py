@@ -110,14 +110,40 @@ class Pipeline:
             return page, visualize_page(pil, page, show_order=True)
         return page
 
+    def _order_boxes(self, page):
+        """Reading-order reorder of every block (in place) + AABBs of the words that pass min_text_size.
+        Same semantics as _pipeline.py:102-133 of the reference, vectorised."""
+        words, boxes = [], []
+        for block in page.blocks:
+            if not block.words:
+                continue
+            # AABBs of all words at once: np.array(polygon, int32) truncates toward zero (_pipeline.py:106)
+            polys = np.array([w.polygon for w in block.words], dtype=np.float64).astype(np.int32)
+            mins, maxs = polys.min(axis=1), polys.max(axis=1)
+            aabbs = [(a[0], a[1], b[0], b[1]) for a, b in zip(mins, maxs)]
+            first = {}
+            for k, bx in enumerate(aabbs):  # "first equal word wins" of the reference's O(n^2) re-match (:113-121)
+                first.setdefault(tuple(int(v) for v in bx), k)
+            order = [first[tuple(int(v) for v in bx)] for bx in sort_boxes_reading_order_with_resolutions(aabbs)]
+            old_words = block.words
+            block.words = [old_words[k] for k in order]
+            for k in order:
+                x0, y0, x1, y1 = aabbs[k]
+                if (x1 - x0) >= self.min_text_size and (y1 - y0) >= self.min_text_size:
+                    words.append(old_words[k])
+                    boxes.append((x0, y0, x1, y1))
+        return words, boxes
+
     def predict_batch(self, images: List[Union[str, np.ndarray]], recognize_text: bool = True, profile: bool = False,
-                      pages_dev=None, _maps_override=None):
+                      pages_dev=None, sub_batches: int = 0, _maps_override=None):
         """Equally sized pages -> list of Pages, same results as per-page `predict`.
 
         MI355X fast path (detector and recogniser are this package's EAST / TRBA): the pages are uploaded once,
-        the detector runs once for the batch, word crops are cut, resized and padded ON THE DEVICE from the resident
-        pages (no host crop, no per-crop upload) and the recogniser runs once over all crops of all pages — while the
-        decode run lengths that enter the confidences still follow the reference's per-page / per-`batch_size` chunking.
+        word crops are cut, resized and padded ON THE DEVICE from the resident pages (no host crop, no per-crop upload)
+        and the recogniser runs over all crops of a sub-batch at once — while the decode run lengths that enter the
+        confidences still follow the reference's per-page / per-`batch_size` chunking.  The batch is processed as
+        `sub_batches` groups on separate HIP streams in a software pipeline, so the host stages of one group (box
+        filters, reading order, crop descriptors) overlap the device work of the others.
         `pages_dev`: optional [N,H,W,3] u8 device tensor already holding `images` (benchmarks: inputs resident in HBM)."""
         native = isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA)
         if not native:
@@ -125,67 +151,82 @@ class Pipeline:
         import torch
 
         from . import ops
-        tm = {}
-        t0 = time.perf_counter()
+        det, rec = self.detector, self.recognizer
+        tm = {"detect_wait+tail": 0.0, "order": 0.0, "crop+enqueue": 0.0, "recognize_wait": 0.0, "assign": 0.0}
         arrays = [read_image(im) for im in images]
+        if len({a.shape for a in arrays}) != 1:
+            raise ValueError("predict_batch needs equally sized pages")
+        N = len(arrays)
         if pages_dev is None:
-            pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(self.detector.device)
-        results = self.detector.predict_batch(arrays, profile=profile, _pages_dev=pages_dev, _maps_override=_maps_override)
-        pages = [self._page_of(r) for r in results]
-        tm["detect"] = time.perf_counter() - t0
-        self.last_profile = tm
-        if not recognize_text:
-            return pages
-        t0 = time.perf_counter()
-        rec = self.recognizer
-        all_words, boxes, page_ids, spans = [], [], [], []
-        for pi, page in enumerate(pages):
-            n0 = len(all_words)
-            for block in page.blocks:
-                if not block.words:
-                    continue
-                # AABBs of all words at once: np.array(polygon, int32) truncates toward zero (_pipeline.py:106)
-                polys = np.array([w.polygon for w in block.words], dtype=np.float64).astype(np.int32)
-                mins, maxs = polys.min(axis=1), polys.max(axis=1)
-                aabbs = [(a[0], a[1], b[0], b[1]) for a, b in zip(mins, maxs)]
-                first = {}
-                for k, bx in enumerate(aabbs):  # "first equal word wins" of the reference's O(n^2) re-match (:113-121)
-                    first.setdefault(tuple(int(v) for v in bx), k)
-                order = [first[tuple(int(v) for v in bx)] for bx in sort_boxes_reading_order_with_resolutions(aabbs)]
-                old_words = block.words
-                block.words = [old_words[k] for k in order]
-                for k in order:
-                    x0, y0, x1, y1 = aabbs[k]
-                    if (x1 - x0) >= self.min_text_size and (y1 - y0) >= self.min_text_size:
-                        all_words.append(old_words[k])
-                        boxes.append((x0, y0, x1, y1))
-                        page_ids.append(pi)
-            spans.append([n0, len(all_words) - n0])
-        tm["order"] = time.perf_counter() - t0
-        if not boxes:
-            return pages
-        t0 = time.perf_counter()
+            pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(det.device)
+        nsub = sub_batches or (4 if N >= 8 else (2 if N >= 4 else 1))
+        nsub = max(1, min(nsub, N))
+        bounds = [(N * k // nsub, N * (k + 1) // nsub) for k in range(nsub)]
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_streams") or len(self._streams) < nsub:
+            self._streams = [torch.cuda.Stream() for _ in range(nsub)]
+        streams = self._streams[:nsub]
         H, W = arrays[0].shape[:2]
-        desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
-        if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
-            all_words = [w for w, k in zip(all_words, keep) if k]
-            kept_pages = np.asarray(page_ids)[keep]
-            spans, n0 = [], 0
-            for pi in range(len(pages)):
-                c = int((kept_pages == pi).sum())
-                spans.append([n0, c])
-                n0 += c
-        if len(desc):
-            canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-            tm["crop"] = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            out = rec.recognize_canvases(canv, spans=[tuple(s) for s in spans if s[1] > 0])
-            tm["recognize"] = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            self._assign(all_words, rec._results(*out))
-            tm["assign"] = time.perf_counter() - t0
+        # stage 1: enqueue every group's detector work (async)
+        det_handles = []
+        for (lo, hi), st in zip(bounds, streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                mo = None if _maps_override is None else (_maps_override[0][lo:hi], _maps_override[1][lo:hi])
+                det_handles.append(det.detect_start(pages_dev[lo:hi], mo))
+        # stage 2: per group — wait for its boxes, host tail + reading order, enqueue crops + recogniser (async)
+        pages, groups = [None] * N, []
+        for (lo, hi), st, dh in zip(bounds, streams, det_handles):
+            with torch.cuda.stream(st):
+                t0 = time.perf_counter()
+                res = det.detect_finish(dh, arrays[lo:hi], profile=profile)
+                tm["detect_wait+tail"] += time.perf_counter() - t0
+                grp = {"words": [], "spans": [], "handle": None}
+                if recognize_text:
+                    t0 = time.perf_counter()
+                    boxes, page_ids = [], []
+                    for pi, r in enumerate(res):
+                        page = self._page_of(r)
+                        pages[lo + pi] = page
+                        words, bxs = self._order_boxes(page)
+                        grp["spans"].append([len(grp["words"]), len(words)])
+                        grp["words"] += words
+                        boxes += bxs
+                        page_ids += [lo + pi] * len(bxs)
+                    tm["order"] += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    if boxes:
+                        desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
+                        if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
+                            grp["words"] = [w for w, k in zip(grp["words"], keep) if k]
+                            kept_pages = np.asarray(page_ids)[keep]
+                            grp["spans"], n0 = [], 0
+                            for pi in range(lo, hi):
+                                c = int((kept_pages == pi).sum())
+                                grp["spans"].append([n0, c])
+                                n0 += c
+                        if len(desc):
+                            canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
+                            grp["handle"] = rec.recognize_start(canv)
+                    tm["crop+enqueue"] += time.perf_counter() - t0
+                else:
+                    for pi, r in enumerate(res):
+                        pages[lo + pi] = self._page_of(r)
+                groups.append(grp)
+        # stage 3: per group — finish the recogniser (sync) and annotate the words
+        for grp, st in zip(groups, streams):
+            if grp["handle"] is not None:
+                with torch.cuda.stream(st):
+                    t0 = time.perf_counter()
+                    out = rec.recognize_finish(grp["handle"], spans=[tuple(s) for s in grp["spans"] if s[1] > 0])
+                    tm["recognize_wait"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                self._assign(grp["words"], rec._results(*out))
+                tm["assign"] += time.perf_counter() - t0
+            main.wait_stream(st)
+        self.last_profile = tm
         if profile:
-            print("Pipeline.predict_batch stages (s):", {k: round(v, 4) for k, v in tm.items()})
+            print("Pipeline.predict_batch host stages (s):", {k: round(v, 4) for k, v in tm.items()})
         return pages
 
     def process_batch(self, images: List[Union[str, np.ndarray, Image.Image]], recognize_text: bool = True, vis: bool = False,

@@ -140,23 +140,21 @@ class EAST:
         return out
 
     # ------------------------------------------------------------------------------------- API
-    def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
-                      sort_reading_order=False, _maps_override=None, _pages_dev=None) -> List[Dict[str, Any]]:
-        imgs = [read_image(im) for im in images]
-        if len({im.shape for im in imgs}) != 1:
-            raise ValueError("predict_batch needs equally sized pages")
+    def detect_start(self, pages_dev: torch.Tensor, maps_override=None):
+        """Enqueue resize + network + decode + LANMS for [N,h,w,3] u8 device pages on the CURRENT stream; no sync."""
+        return self.detect_device(pages_dev, maps_override)
+
+    def detect_finish(self, handle, imgs, vis=False, profile=False, return_maps=False, sort_reading_order=False):
+        """Wait for `handle` (from detect_start), then the host tail (infer.py:340-390) -> list of result dicts."""
         t0 = time.time()
-        pages = _pages_dev if _pages_dev is not None else \
-            torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
-        score, geo, boxes, nbox, counts = self.detect_device(pages, _maps_override)
-        t_launch = time.time() - t0
+        score, geo, boxes, nbox, counts = handle
         nbox_h = nbox.cpu().numpy()
         counts_h = counts.cpu().numpy()
         if np.any(counts_h < 0):
             raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
         boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
         if profile:
-            print(f"  Model inference + decode + NMS (device): {time.time() - t0:.3f}s")
+            print(f"  Model inference + decode + NMS (device wait): {time.time() - t0:.3f}s")
             print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
         t_dev = time.time() - t0
         results = []
@@ -172,8 +170,17 @@ class EAST:
                 "score_map": score[n].cpu().numpy() if return_maps else None,
                 "geo_map": geo[n].permute(2, 0, 1).contiguous().cpu().numpy() if return_maps else None,
             })
-        self.last_profile = {"launch": t_launch, "device_done": t_dev, "total": time.time() - t0}
+        self.last_profile = {"device_wait": t_dev, "host_tail": time.time() - t0 - t_dev}
         return results
+
+    def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
+                      sort_reading_order=False, _maps_override=None, _pages_dev=None) -> List[Dict[str, Any]]:
+        imgs = [read_image(im) for im in images]
+        if len({im.shape for im in imgs}) != 1:
+            raise ValueError("predict_batch needs equally sized pages")
+        pages = _pages_dev if _pages_dev is not None else \
+            torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
+        return self.detect_finish(self.detect_start(pages, _maps_override), imgs, vis, profile, return_maps, sort_reading_order)
 
     def predict(self, img_or_path: Union[str, Path, np.ndarray], vis: bool = False, profile: bool = False,
                 return_maps: bool = False, sort_reading_order: bool = False) -> Dict[str, Any]:

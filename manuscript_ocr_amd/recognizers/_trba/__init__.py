@@ -134,24 +134,14 @@ class TRBA:
         return np.stack([resize_and_pad(self._load_rgb(im), self.img_h, self.img_w) for im in images])
 
     # ------------------------------------------------------------------------------------- device path
-    def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
-                           spans=None, return_logits=False):
-        """canvases [N,img_h,img_w,3] u8 on device -> (ids [N,steps] i32, t_run [N] i32, conf [N] f32[, logits]) on host.
-
-        `spans` = [(start, count), ...] groups of rows that the reference would have passed to ONE predict() call
-        (one page each); inside a span rows are chunked by `batch_size` and every chunk stops at its own step
-        (greedy: first step where every row emits EOS; beam: once every beam of every row is finished) — that run
-        length enters the confidences.  The device batches (`device_batch` rows) are independent of that chunking.
-        Confidences are reduced on the device (msocr_seq_confidence): only ids and one float per row cross PCIe."""
+    def recognize_start(self, canvases_dev: torch.Tensor, mode="beam", beam_size=8, temperature=1.7, alpha=0.9):
+        """Phase 1 — encode + full-length decode of [N,img_h,img_w,3] u8 device canvases, enqueued on the CURRENT
+        stream without any synchronisation.  Returns a handle for `recognize_finish`."""
         if mode not in ("greedy", "beam"):
             raise ValueError(f"Unknown mode: {mode}")
-        from ... import _native as nat
-        from ... import ops
         N = canvases_dev.shape[0]
-        spans = spans if spans is not None else [(0, N)]
-        steps = self.max_length + 1 if mode == "greedy" else self.max_length
         parts = []
-        for s in range(0, N, self.device_batch):  # phase 1: encode + full-length decode, results stay on the device
+        for s in range(0, N, self.device_batch):
             cv = canvases_dev[s:s + self.device_batch]
             batch_H, proj_H = self.model.encode(cv)
             if mode == "greedy":
@@ -159,7 +149,21 @@ class TRBA:
             else:
                 parts.append(self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
                                              self.blank_id))
-        trun = np.empty(N, dtype=np.int32)  # phase 2: the reference's per-chunk run length
+        return {"parts": parts, "N": N, "mode": mode, "beam": beam_size}
+
+    def recognize_finish(self, handle, batch_size=32, spans=None, return_logits=False):
+        """Phases 2-3 — derive the reference's per-chunk run lengths, back-track (beam) and reduce confidences.
+
+        `spans` = [(start, count), ...] groups of rows that the reference would have passed to ONE predict() call
+        (one page each); inside a span rows are chunked by `batch_size` and every chunk stops at its own step
+        (greedy: first step where every row emits EOS; beam: once every beam of every row is finished) — that run
+        length enters the confidences.  Only ids and one float per row cross PCIe (msocr_seq_confidence)."""
+        from ... import _native as nat
+        from ... import ops
+        parts, N, mode, beam_size = handle["parts"], handle["N"], handle["mode"], handle["beam"]
+        spans = spans if spans is not None else [(0, N)]
+        steps = self.max_length + 1 if mode == "greedy" else self.max_length
+        trun = np.empty(N, dtype=np.int32)
         if mode == "greedy":
             ids_h = np.concatenate([p[1].cpu().numpy() for p in parts])
             for s0, cnt in spans:
@@ -175,7 +179,7 @@ class TRBA:
                     trun[c0:c1] = fin_h[c0:c1].max()
         trun_dev = torch.from_numpy(trun).to(self.device)
         ids_out, conf_out, logit_out = [], [], []
-        for k, s in enumerate(range(0, N, self.device_batch)):  # phase 3: back-track (beam) + confidence, per device batch
+        for k, s in enumerate(range(0, N, self.device_batch)):
             B = min(self.device_batch, N - s)
             tr = trun_dev[s:s + B]
             if mode == "greedy":
@@ -194,6 +198,11 @@ class TRBA:
         if return_logits:
             return ids_h, trun, conf_h, np.concatenate(logit_out)
         return ids_h, trun, conf_h
+
+    def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
+                           spans=None, return_logits=False):
+        """canvases [N,img_h,img_w,3] u8 on device -> (ids [N,steps] i32, t_run [N] i32, conf [N] f32[, logits]) on host."""
+        return self.recognize_finish(self.recognize_start(canvases_dev, mode, beam_size, temperature, alpha), batch_size, spans, return_logits)
 
     def _results(self, ids, trun, conf) -> List[Dict[str, Any]]:
         """__init__.py:415-432: decode_tokens over the t_run generated ids; confidence computed on the device."""
