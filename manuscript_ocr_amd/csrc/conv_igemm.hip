@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 
   u32x4 ra[A_IT], rb[B_IT];
+  uint32_t a_ok[A_IT];
 
   auto load_tile = [&](int kt) {
     const int tap = kt / p.cin_tiles;
@@ -151,9 +152,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     for (int i = 0; i < A_IT; ++i) {
       const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(p.in + (a_base[i] + koff) * ES);
-      ra[i] = v;
+      // branch-free: out-of-image taps read the (always valid) first 16 bytes of the tensor and are masked to zero
+      const long off = ok ? (a_base[i] + koff) : 0;
+      ra[i] = *reinterpret_cast<const u32x4*>(p.in + off * ES);
+      a_ok[i] = ok ? 0xffffffffu : 0u;  // applied when the tile is written to LDS: the load itself stays in flight
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = row0 + i * RPP;
-      *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = ra[i];
+      u32x4 v = ra[i];
+      v[0] &= a_ok[i]; v[1] &= a_ok[i]; v[2] &= a_ok[i]; v[3] &= a_ok[i];
+      *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = v;
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
@@ -189,29 +193,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   store_tile(0);
   __syncthreads();
 
+  auto read_frags = [&](const unsigned char* sa, const unsigned char* sb, int q, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
+    const int c = 2 * q + half;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WM + i * 32 + r32;
+      fa[i] = *reinterpret_cast<const u32x4*>(sa + row * BKB + ((c ^ swz<BKB>(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * WN + j * 32 + r32;
+      fb[j] = *reinterpret_cast<const u32x4*>(sb + row * BKB + ((c ^ swz<BKB>(row)) << 4));
+    }
+  };
+  constexpr int NQ = CPR / 2;
   for (int kt = 0; kt < p.ktiles; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
+    u32x4 fa[2][TM], fb[2][TN];
+    read_frags(sa, sb, 0, fa[0], fb[0]);
 #pragma unroll
-    for (int q = 0; q < CPR / 2; ++q) {
-      const int c = 2 * q + half;
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WM + i * 32 + r32;
-        fa[i] = *reinterpret_cast<const u32x4*>(sa + row * BKB + ((c ^ swz<BKB>(row)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WN + j * 32 + r32;
-        fb[j] = *reinterpret_cast<const u32x4*>(sb + row * BKB + ((c ^ swz<BKB>(row)) << 4));
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 1 < NQ) {  // LDS reads of the next k-group are issued BEFORE this group's MFMAs and stay pinned there
+        read_frags(sa, sb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
     }
     if (kt + 1 < p.ktiles) store_tile(cur ^ 1);
     __syncthreads();

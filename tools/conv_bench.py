@@ -1,0 +1,38 @@
+"""Micro-benchmark of msocr_conv2d on the dominant shapes of the pipeline (dev tool, GPU only)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from manuscript_ocr_amd import ops
+
+SHAPES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (2048, 4, 13, 512, 512, 3, 1, 1),     # TRBA layer3/4 3x3 (45 launches/step)
+    (2048, 8, 25, 256, 256, 3, 1, 1),     # TRBA layer2
+    (2048, 16, 50, 64, 128, 3, 1, 1),     # TRBA conv0b
+    (4, 384, 512, 64, 256, 1, 1, 0),      # EAST layer1 1x1 64->256 (K=64)
+    (4, 384, 512, 64, 64, 3, 1, 1),       # EAST layer1 3x3
+    (4, 96, 128, 256, 256, 3, 1, 1),      # EAST layer3 3x3
+    (4, 96, 128, 256, 1024, 1, 1, 0),     # EAST layer3 1x1
+]
+
+def main():
+    dt = torch.float32 if (len(sys.argv) < 2 or sys.argv[1] == "fp32") else torch.bfloat16
+    for (N, H, W, Cin, Cout, k, s, p) in SHAPES:
+        x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
+        w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
+        b = torch.randn(Cout, device="cuda")
+        out = ops.conv2d(x, w, b, (s, s), (p, p), True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 10
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d(x, w, b, (s, s), (p, p), True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        Ho, Wo = out.shape[1], out.shape[2]
+        fl = 2.0 * N * Ho * Wo * Cout * k * k * Cin
+        print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{k}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s")
+
+if __name__ == "__main__":
+    main()
