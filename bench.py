@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sub-batches", type=int, default=0, help="sub-batch groups pipelined on separate streams (0 = auto)")
+    ap.add_argument("--serialize-streams", action="store_true",
+                    help="run the sub-batch pipeline on ONE stream (no cross-stream kernel overlap): per-kernel profiling mode")
     return ap.parse_args()
 
 
@@ -76,6 +79,8 @@ def main():
     det = EAST(state_dict=esd, target_size=(W, H), device="cuda", precision=a.precision)
     rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
+    if pipe is not None and a.serialize_streams:
+        pipe.serialize_streams = True
 
     # synthetic pages + injected maps of THIS rank's shard (global page id = rank*NP + i)
     pages, scores, geos = [], [], []
@@ -89,7 +94,7 @@ def main():
 
     def step():
         if pipe is not None:
-            return pipe.predict_batch(pages, pages_dev=pages_dev, _maps_override=maps_dev)
+            return pipe.predict_batch(pages, pages_dev=pages_dev, sub_batches=a.sub_batches, _maps_override=maps_dev)
         return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
 
     def barrier():
@@ -153,39 +158,70 @@ def main():
         res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}
         res["east_stage_s_last_step"] = {k: round(v, 4) for k, v in det.last_profile.items()}
     if rank == 0 and not a.no_roofline:
-        # live HIP-event timing of every implicit-GEMM launch (events on the launch stream = torch's current stream)
-        ops.PROFILE = []
-        for _ in range(a.steps):
-            step()
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-        ms = np.array([e0.elapsed_time(e1) for e0, e1, _, _ in prof])
-        fl = np.array([f for _, _, f, _ in prof])
-        tf = fl.sum() / (ms.sum() * 1e-3) / 1e12
+        # Live HIP-event timing of every implicit-GEMM launch (events on the launch stream = torch's current stream).
         peak = PEAK_TFLOPS[a.precision]
-        if os.environ.get("MSOCR_DUMP_CONV"):
-            agg = {}
-            for (e0, e1, f, tag), m in zip(prof, ms):
-                a_ = agg.setdefault(tag, [0, 0.0, 0.0])
-                a_[0] += 1
-                a_[1] += m
-                a_[2] += f
-            with open(os.environ["MSOCR_DUMP_CONV"], "w") as fh:
-                for tag, (cnt, m, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
+
+        def instrumented(serialize):
+            if pipe is not None:
+                pipe.serialize_streams = serialize
+            step()  # settle allocator pools of this mode
+            torch.cuda.synchronize()
+            ref = torch.cuda.Event(enable_timing=True)
+            ref.record()
+            ops.PROFILE = []
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            prof, ops.PROFILE = ops.PROFILE, None
+            if pipe is not None:
+                pipe.serialize_streams = a.serialize_streams
+            iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1, _, _ in prof)
+            fl = float(sum(f for _, _, f, _ in prof))
+            dur = np.array([e - s for s, e in iv])
+            union, cs, ce = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > ce:
+                    union += ce - cs
+                    cs, ce = s_, e_
+                else:
+                    ce = max(ce, e_)
+            union += ce - cs
+            return prof, fl, dur, union
+
+        # (1) the timed configuration: sub-batch streams overlap, so a launch's event-to-event time includes the other
+        #     streams' kernels sharing the chip.  Chip-level rate = FLOP / union of the intervals in which >= 1 conv runs.
+        prof, fl, dur, union = instrumented(a.serialize_streams)
+        tf = fl / (union * 1e-3) / 1e12
         res["roofline"] = {
-            "kernel": "conv_igemm_kernel (all implicit-GEMM launches of a step, FLOP-weighted)",
+            "kernel": "conv_igemm_kernel (every implicit-GEMM launch of a step; achieved = algorithmic FLOP / time in which "
+                      "at least one such launch is executing, sub-batch streams overlapping as in the timed region)",
             "bound": "mfma",
             "achieved": tf,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": tf / peak,
-            "traffic": None,
+            "traffic": pmc_traffic() if (a.workload == "pipeline" and a.precision == "fp32" and not a.pages and not a.sub_batches) else None,
             "launches_per_step": len(prof) // a.steps,
-            "avg_launch_ms": float(ms.mean()),
-            "conv_ms_per_step": float(ms.sum() / a.steps),
-            "alg_gflop_per_step": float(fl.sum() / a.steps / 1e9),
+            "avg_launch_ms": float(dur.mean()),
+            "conv_busy_ms_per_step": float(union / a.steps),
+            "alg_gflop_per_step": fl / a.steps / 1e9,
         }
+        # (2) the same launches on ONE stream: isolated per-launch durations (FLOP-weighted rate of a launch running alone)
+        if pipe is not None and not a.serialize_streams:
+            prof2, fl2, dur2, _ = instrumented(True)
+            tf2 = fl2 / (dur2.sum() * 1e-3) / 1e12
+            res["roofline"]["isolated"] = {"achieved": tf2, "frac": tf2 / peak, "avg_launch_ms": float(dur2.mean()),
+                                           "conv_ms_per_step": float(dur2.sum() / a.steps)}
+        if os.environ.get("MSOCR_DUMP_CONV"):
+            agg = {}
+            for (e0, e1, f, tag) in prof:
+                a_ = agg.setdefault(tag, [0, 0.0, 0.0])
+                a_[0] += 1
+                a_[1] += e0.elapsed_time(e1)
+                a_[2] += f
+            with open(os.environ["MSOCR_DUMP_CONV"], "w") as fh:
+                for tag, (cnt, m, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out)
@@ -194,6 +230,18 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per step of the conv launches from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    rocprofv3 --pmc passes of this same command; bench.py cannot run the profiler on itself, so the committed
+    measurement is reported, or null when absent / not for this workload)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_step"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=25.0):

@@ -106,7 +106,8 @@ int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int dtype, flo
 
 /* One bidirectional LSTM layer + Linear (BidirectionalLSTM.forward, model/model.py:9-21).
  * xproj [B][T][2][4H] f32 = x W_ih^T + b_ih + b_hh for both directions (an msocr_conv2d 1x1 / GEMM);
- * w_hh_t [2][H][4H] f32 (transposed, gate order i,f,g,o); hcat_out [B][T][2H] f32. */
+ * w_hh_t [2][H][H][4] f32 = weight_hh^T with the 4 gates (i,f,g,o) of unit j interleaved: [dir][k][j][gate];
+ * hcat_out [B][T][2H] f32. */
 int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out,
                            void* stream);
 
@@ -114,10 +115,10 @@ typedef struct msocr_attn_weights {
   const float* h2h_wt;   /* [H][H]   h2h.weight^T */
   const float* h2h_b;    /* [H] */
   const float* score_w;  /* [H] */
-  const float* wih_ctx_t;/* [H][4H]  rnn.weight_ih[:, :H]^T */
-  const float* wih_tok;  /* [V][4H]  rnn.weight_ih[:, H:]^T (one-hot matmul == row gather) */
-  const float* whh_t;    /* [H][4H] */
-  const float* b_gates;  /* [4H] b_ih + b_hh */
+  const float* wih_ctx_t;/* [H][H][4]  rnn.weight_ih[:, :H]^T, gates of unit j interleaved: [k][j][gate] */
+  const float* wih_tok;  /* [V][H][4]  rnn.weight_ih[:, H:]^T (one-hot matmul == row gather): [token][j][gate] */
+  const float* whh_t;    /* [H][H][4]  rnn.weight_hh^T: [k][j][gate] */
+  const float* b_gates;  /* [H][4]     b_ih + b_hh: [j][gate] */
   const float* gen_wt;   /* [H][V]  generator.weight^T */
   const float* gen_b;    /* [V] */
 } msocr_attn_weights;

@@ -173,11 +173,11 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
       const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[cur][k][0]);
       const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[cur][k][4]);
       const float hv[RB] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wt[((long)k * H + j) * 4]);  // gates i,f,g,o of unit j, one 16-B load
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float w = wt[(long)k * G + g * H + j];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) acc[g][r] = fmaf(w, hv[r], acc[g][r]);
+        for (int r = 0; r < RB; ++r) acc[g][r] = fmaf(w4[g], hv[r], acc[g][r]);
       }
     }
 #pragma unroll
@@ -285,25 +285,30 @@ __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, 
   __syncthreads();
   // (e) LSTMCell gates: W_ih[:, :H] ctx + W_ih[:, H+tok] + W_hh h + (b_ih + b_hh); thread j owns unit j
   float g4[4][K];
+  {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(&a.w.b_gates[j * 4]);
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int r = 0; r < K; ++r) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(&a.w.wih_tok[((long)tok[r] * H + j) * 4]);
 #pragma unroll
-    for (int r = 0; r < K; ++r) g4[g][r] = a.w.b_gates[g * H + j] + a.w.wih_tok[(long)tok[r] * 4 * H + g * H + j];
-  for (int k = 0; k < H; ++k) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float w = a.w.wih_ctx_t[(long)k * 4 * H + g * H + j];
-#pragma unroll
-      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w, sctx[k][r], g4[g][r]);
+      for (int g = 0; g < 4; ++g) g4[g][r] = b4[g] + t4[g];
     }
   }
+#pragma unroll 2
   for (int k = 0; k < H; ++k) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&a.w.wih_ctx_t[((long)k * H + j) * 4]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float w = a.w.whh_t[(long)k * 4 * H + g * H + j];
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w, sh[k][r], g4[g][r]);
-    }
+      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w4[g], sctx[k][r], g4[g][r]);
+  }
+#pragma unroll 2
+  for (int k = 0; k < H; ++k) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&a.w.whh_t[((long)k * H + j) * 4]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w4[g], sh[k][r], g4[g][r]);
   }
   __syncthreads();  // everyone finished reading the old h
 #pragma unroll

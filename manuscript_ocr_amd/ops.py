@@ -74,7 +74,7 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout and bias.is_contiguous()
     prof = PROFILE
-    if prof is not None:
+    if prof is not None:  # events are recorded on the launch stream (torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rp,
@@ -212,9 +212,9 @@ def mean_over_h(x):
 
 
 def bilstm_recurrent(xproj, whh_t, B, T, H):
-    """xproj [B*T, 2*4H] f32 (= [B][T][2][4H]), whh_t [2,H,4H] f32 -> hcat [B,T,2H] f32."""
+    """xproj [B*T, 2*4H] f32 (= [B][T][2][4H]), whh_t [2,H,H,4] f32 (gate-interleaved) -> hcat [B,T,2H] f32."""
     _need_cuda(xproj, whh_t)
-    assert xproj.is_contiguous() and xproj.numel() == B * T * 8 * H and whh_t.shape == (2, H, 4 * H) and whh_t.is_contiguous()
+    assert xproj.is_contiguous() and xproj.numel() == B * T * 8 * H and whh_t.shape == (2, H, H, 4) and whh_t.is_contiguous()
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=xproj.device)
     nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
     return out

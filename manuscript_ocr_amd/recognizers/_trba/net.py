@@ -30,6 +30,13 @@ def _fold(sd, conv_key, bn_key):
     return w * s.view(-1, 1, 1, 1), beta - mean * s
 
 
+def _gate_interleave(w_t, H):
+    """[K, 4H] (columns = gate-major i,f,g,o blocks of H units) -> [K, H, 4]: the 4 gates of unit j adjacent,
+    so a lane fetches them with one 16-byte load."""
+    K = w_t.shape[0]
+    return w_t.reshape(K, 4, H).permute(0, 2, 1).contiguous()
+
+
 LAYER_SPEC = (("layer1", 1, 2), ("layer2", 2, 1), ("layer3", 5, 2), ("layer4", 3, 1))
 
 
@@ -73,8 +80,8 @@ class TrbaNet:
             w_ih = torch.cat([sd[p + "rnn.weight_ih_l0"], sd[p + "rnn.weight_ih_l0_reverse"]]).float()  # [2*4H, In]
             b = torch.cat([sd[p + "rnn.bias_ih_l0"] + sd[p + "rnn.bias_hh_l0"],
                            sd[p + "rnn.bias_ih_l0_reverse"] + sd[p + "rnn.bias_hh_l0_reverse"]]).float()
-            whh_t = torch.stack([sd[p + "rnn.weight_hh_l0"].float().t().contiguous(),
-                                 sd[p + "rnn.weight_hh_l0_reverse"].float().t().contiguous()])  # [2][H][4H]
+            whh_t = torch.stack([_gate_interleave(sd[p + "rnn.weight_hh_l0"].float().t(), H),
+                                 _gate_interleave(sd[p + "rnn.weight_hh_l0_reverse"].float().t(), H)])  # [2][H(k)][H(j)][4]
             self.rnn.append({
                 "w_ih": w_ih.view(8 * H, 1, 1, -1).contiguous().to(dev), "b": b.contiguous().to(dev),
                 "whh_t": whh_t.contiguous().to(dev),
@@ -89,10 +96,10 @@ class TrbaNet:
             "h2h_wt": sd[a + "h2h.weight"].float().t().contiguous().to(dev),
             "h2h_b": sd[a + "h2h.bias"].float().contiguous().to(dev),
             "score_w": sd[a + "score.weight"].float().view(H).contiguous().to(dev),
-            "wih_ctx_t": w_ih[:, :H].t().contiguous().to(dev),
-            "wih_tok": w_ih[:, H:].t().contiguous().to(dev),
-            "whh_t": sd[a + "rnn.weight_hh"].float().t().contiguous().to(dev),
-            "b_gates": (sd[a + "rnn.bias_ih"] + sd[a + "rnn.bias_hh"]).float().contiguous().to(dev),
+            "wih_ctx_t": _gate_interleave(w_ih[:, :H].t(), H).to(dev),
+            "wih_tok": _gate_interleave(w_ih[:, H:].t(), H).to(dev),
+            "whh_t": _gate_interleave(sd[a + "rnn.weight_hh"].float().t(), H).to(dev),
+            "b_gates": _gate_interleave((sd[a + "rnn.bias_ih"] + sd[a + "rnn.bias_hh"]).float().view(1, 4 * H), H).view(H, 4).contiguous().to(dev),
             "gen_wt": sd["attn.generator.weight"].float().t().contiguous().to(dev),
             "gen_b": sd["attn.generator.bias"].float().contiguous().to(dev),
         }
@@ -166,8 +173,16 @@ class TrbaNet:
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
         fin = torch.empty((B,), dtype=torch.int32, device=self.device)
         lp = None
-        if alpha > 0:  # model.py:160, evaluated in Python double then applied in f32
-            lp = torch.tensor([((5.0 + (t + 1)) ** alpha) / (6.0 ** alpha) for t in range(steps)], dtype=torch.float32).to(self.device)
+        if alpha > 0:  # model.py:160, evaluated in Python double then applied in f32; cached: an H2D copy here would make
+            #            the host wait for every encoder kernel already queued on this stream
+            key = (float(alpha), steps)
+            if not hasattr(self, "_lp_cache"):
+                self._lp_cache = {}
+            if key not in self._lp_cache:
+                self._lp_cache[key] = torch.tensor([((5.0 + (t + 1)) ** alpha) / (6.0 ** alpha) for t in range(steps)],
+                                                   dtype=torch.float32).to(self.device)
+                torch.cuda.synchronize()
+            lp = self._lp_cache[key]
         nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
                                             beam_size, lp.data_ptr() if lp is not None else None, float(temperature), sos_id, eos_id,
                                             -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(), ops._stream()),

@@ -130,3 +130,38 @@ def test_predict_batch_equals_per_page_predict(gpu):
         cb = [w.recognition_confidence for w in pb.blocks[0].words]
         assert all((x is None) == (y is None) for x, y in zip(ca, cb))
         np.testing.assert_allclose([x for x in ca if x is not None], [y for y in cb if y is not None], atol=1e-6)
+
+
+def test_checkpoint_files_load_like_the_reference(gpu, tmp_path):
+    """a19: EAST takes a raw state_dict file (east.py:130-133); TRBA takes a raw state_dict or {"model_state": ...}
+    (training/utils.py:54-59) with the config auto-discovered next to the weights (__init__.py:195-205)."""
+    import json
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import east_model as oem
+    from oracle import trba_model as otm
+    esd, tsd = oem.synth_east_state_dict(seed=3), otm.synth_trba_state_dict(194, 256, seed=3)
+    torch.save(esd, tmp_path / "east.pth")
+    det_f = EAST(weights_path=str(tmp_path / "east.pth"), target_size=(160, 128))
+    det_m = EAST(state_dict=esd, target_size=(160, 128))
+    page = synth.synth_page(2, 128, 160)[0]
+    a, b = det_f.predict(page, return_maps=True), det_m.predict(page, return_maps=True)
+    assert np.array_equal(a["score_map"], b["score_map"]) and np.array_equal(a["geo_map"], b["geo_map"])
+    assert set(a) == {"page", "vis_image", "score_map", "geo_map"} and det_f.device == "cuda"
+    assert a["score_map"].shape == (32, 40) and a["geo_map"].shape == (8, 32, 40)
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    torch.save({"model_state": tsd, "epoch": 3}, tmp_path / "trba.pth")
+    json.dump(cfg, open(tmp_path / "trba.json", "w"))
+    rec_f = TRBA(weights_path=str(tmp_path / "trba.pth"))          # alias + auto-discovered <weights>.json
+    rec_m = TRBA(state_dict=tsd, config=cfg)
+    assert (rec_f.img_h, rec_f.img_w, rec_f.max_length) == (32, 100, 25) and rec_f.device.type == "cuda"
+    crops = list(synth.synth_crops(1, 5, 32, 100))
+    assert rec_f.predict(crops, mode="greedy") == rec_m.predict(crops, mode="greedy")
+    assert rec_f.predict(crops[0])[0]["text"] == rec_m.predict(crops)[0]["text"]   # single image, beam default
+    with pytest.raises(ValueError):
+        rec_f.predict(crops, mode="sampling")
+    with pytest.raises(TypeError):
+        det_f.predict(12345)
+    with pytest.raises(FileNotFoundError):
+        det_f.predict(str(tmp_path / "missing.jpg"))

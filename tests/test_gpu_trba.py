@@ -58,7 +58,8 @@ def test_se_residual_and_bilstm_ops(env):
         w_ih = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]])
         bias = torch.cat([sd["bias_ih_l0"] + sd["bias_hh_l0"], sd["bias_ih_l0_reverse"] + sd["bias_hh_l0_reverse"]])
         xproj = (xs.reshape(B * T, In) @ w_ih.t() + bias).contiguous()
-        whh_t = torch.stack([sd["weight_hh_l0"].t().contiguous(), sd["weight_hh_l0_reverse"].t().contiguous()])
+        il = lambda w: w.t().reshape(H, 4, H).permute(0, 2, 1).contiguous()  # [k][j][gate]
+        whh_t = torch.stack([il(sd["weight_hh_l0"]), il(sd["weight_hh_l0_reverse"])])
     got = ops.bilstm_recurrent(xproj.cuda(), whh_t.cuda(), B, T, H).cpu()
     assert (got - ref_h).abs().max().item() < 2e-5
 
