@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msocr.h"
 
@@ -168,16 +169,21 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g][r] = xp[g * H + j];
     }
-#pragma unroll 4
-    for (int k = 0; k < H; ++k) {
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[cur][k][0]);
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[cur][k][4]);
-      const float hv[RB] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wt[((long)k * H + j) * 4]);  // gates i,f,g,o of unit j, one 16-B load
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += 8) {
+      f32x4 wq[8];  // gates i,f,g,o of unit j: 8 x 16-B loads in flight per lane
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int u = 0; u < 8; ++u) wq[u] = *reinterpret_cast<const f32x4*>(&wt[((long)(k0 + u) * H + j) * 4]);
 #pragma unroll
-        for (int r = 0; r < RB; ++r) acc[g][r] = fmaf(w4[g], hv[r], acc[g][r]);
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[cur][k0 + u][0]);
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[cur][k0 + u][4]);
+        const float hv[RB] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r) acc[g][r] = fmaf(wq[u][g], hv[r], acc[g][r]);
+        }
       }
     }
 #pragma unroll
@@ -199,8 +205,11 @@ extern "C" int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, i
 }
 
 // --------------------------------------------------------------------------------------------- attention decoder
-// One workgroup (256 threads, H == 256) per batch row; K = 1 (greedy) or beam states.
-// LDS: batch_H[T][H], proj_H[T][H] of this row, h / ctx as [k][r], ph[r][j], alpha[r][t], logits[r][v].
+// One workgroup (256 threads, H == 256) owns NB batch rows for the whole step loop; KR = NB*RPB state rows
+// (RPB = 1 greedy, 8 beam).  Thread j owns hidden unit j (4 gates x KR rows in registers); weights are
+// pre-transposed so lane j streams column j (gate-interleaved: one 16-B load per k); every weight element a
+// workgroup fetches from L2 is used for KR rows, so NB = 2 halves the L2 traffic that bounds this kernel.
+// LDS: batch_H / proj_H of the NB rows [NB][T][H], h and ctx as [k][row], ph[row][j], alpha[row][t], logits[row][v].
 #define ATT_H 256
 #define ATT_KMAX 8
 
@@ -220,36 +229,42 @@ struct AttnArgs {
   int32_t* fin_step;    // beam: [B]
 };
 
-template <int K>
-__device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, const float* sH, const float* sP, float (*sh)[ATT_KMAX],
-                                                    float (*sctx)[ATT_KMAX], float (*sph)[ATT_H], float (*salpha)[64],
-                                                    float (*slog)[256], float (&c)[K], const int* tok, int T, int V) {
+template <int KR, int RPB>
+__device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, const float* sH, const float* sP, float (*sh)[KR],
+                                                    float (*sctx)[KR], float (*sph)[ATT_H], float (*salpha)[64],
+                                                    float (*slog)[256], float (&c)[KR], const int* tok, int T, int V) {
   constexpr int H = ATT_H;
   const int j = tid;
   // (a) ph[r][j] = h2h(h)[j]
   {
-    float acc[K];
+    float acc[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) acc[r] = a.w.h2h_b[j];
-    for (int k = 0; k < H; ++k) {
-      const float w = a.w.h2h_wt[(long)k * H + j];
+    for (int r = 0; r < KR; ++r) acc[r] = a.w.h2h_b[j];
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += 8) {
+      float wq[8];
 #pragma unroll
-      for (int r = 0; r < K; ++r) acc[r] = fmaf(w, sh[k][r], acc[r]);
+      for (int u = 0; u < 8; ++u) wq[u] = a.w.h2h_wt[(long)(k0 + u) * H + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) acc[r] = fmaf(wq[u], sh[k0 + u][r], acc[r]);
     }
 #pragma unroll
-    for (int r = 0; r < K; ++r) sph[r][j] = acc[r];
+    for (int r = 0; r < KR; ++r) sph[r][j] = acc[r];
   }
   __syncthreads();
   // (b) e[r][t] = score . tanh(proj_H[t] + ph[r]) : one wave per (r,t) pair, lanes over j
   {
     const int lane = tid & 63, wv = tid >> 6;
-    for (int p = wv; p < K * T; p += 4) {
+    for (int p = wv; p < KR * T; p += 4) {
       const int r = p / T, t = p - r * T;
+      const float* pP = sP + (r / RPB) * T * H;
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < H / 64; ++q) {
         const int jj = lane + 64 * q;
-        s = fmaf(a.w.score_w[jj], tanhf(sP[t * H + jj] + sph[r][jj]), s);
+        s = fmaf(a.w.score_w[jj], tanhf(pP[t * H + jj] + sph[r][jj]), s);
       }
       s = wave_sum(s);
       if (lane == 0) salpha[r][t] = s;
@@ -257,7 +272,7 @@ __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, 
   }
   __syncthreads();
   // (c) softmax over t (T <= 64): thread r
-  if (tid < K) {
+  if (tid < KR) {
     float m = -INFINITY;
     for (int t = 0; t < T; ++t) m = fmaxf(m, salpha[tid][t]);
     float sum = 0.f;
@@ -271,48 +286,62 @@ __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, 
   __syncthreads();
   // (d) ctx[r][j] = sum_t alpha[r][t] * batch_H[t][j]
   {
-    float acc[K];
+    float acc[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) acc[r] = 0.f;
+    for (int r = 0; r < KR; ++r) acc[r] = 0.f;
     for (int t = 0; t < T; ++t) {
-      const float hv = sH[t * H + j];
 #pragma unroll
-      for (int r = 0; r < K; ++r) acc[r] = fmaf(salpha[r][t], hv, acc[r]);
+      for (int nb = 0; nb < KR / RPB; ++nb) {
+        const float hv = sH[(nb * T + t) * H + j];
+#pragma unroll
+        for (int q = 0; q < RPB; ++q) acc[nb * RPB + q] = fmaf(salpha[nb * RPB + q][t], hv, acc[nb * RPB + q]);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < K; ++r) sctx[j][r] = acc[r];
+    for (int r = 0; r < KR; ++r) sctx[j][r] = acc[r];
   }
   __syncthreads();
   // (e) LSTMCell gates: W_ih[:, :H] ctx + W_ih[:, H+tok] + W_hh h + (b_ih + b_hh); thread j owns unit j
-  float g4[4][K];
+  float g4[4][KR];
   {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(&a.w.b_gates[j * 4]);
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
+    for (int r = 0; r < KR; ++r) {
       const f32x4 t4 = *reinterpret_cast<const f32x4*>(&a.w.wih_tok[((long)tok[r] * H + j) * 4]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) g4[g][r] = b4[g] + t4[g];
     }
   }
-#pragma unroll 2
-  for (int k = 0; k < H; ++k) {
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&a.w.wih_ctx_t[((long)k * H + j) * 4]);
+  // weights stream from L2: keep PF 16-byte loads in flight per lane (the FMAs of a k-group run under the next group's loads)
+  constexpr int PF = 4;
+  auto gate_pass = [&](const float* __restrict__ wt, float (*x)[KR]) {
+    f32x4 wq[PF];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int u = 0; u < PF; ++u) wq[u] = *reinterpret_cast<const f32x4*>(&wt[((long)u * H + j) * 4]);
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += PF) {
+      f32x4 wn[PF];
+      if (k0 + PF < H) {
 #pragma unroll
-      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w4[g], sctx[k][r], g4[g][r]);
-  }
-#pragma unroll 2
-  for (int k = 0; k < H; ++k) {
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&a.w.whh_t[((long)k * H + j) * 4]);
+        for (int u = 0; u < PF; ++u) wn[u] = *reinterpret_cast<const f32x4*>(&wt[((long)(k0 + PF + u) * H + j) * 4]);
+      }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < PF; ++u)
 #pragma unroll
-      for (int r = 0; r < K; ++r) g4[g][r] = fmaf(w4[g], sh[k][r], g4[g][r]);
-  }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < KR; ++r) g4[g][r] = fmaf(wq[u][g], x[k0 + u][r], g4[g][r]);
+      if (k0 + PF < H) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) wq[u] = wn[u];
+      }
+    }
+  };
+  gate_pass(a.w.wih_ctx_t, sctx);
+  gate_pass(a.w.whh_t, sh);
   __syncthreads();  // everyone finished reading the old h
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
+  for (int r = 0; r < KR; ++r) {
     const float ig = sigmoidf_(g4[0][r]), fg = sigmoidf_(g4[1][r]), gg = tanhf(g4[2][r]), og = sigmoidf_(g4[3][r]);
     c[r] = fg * c[r] + ig * gg;
     sh[j][r] = og * tanhf(c[r]);
@@ -320,16 +349,21 @@ __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, 
   __syncthreads();
   // (f) generator logits[r][v]
   if (tid < V) {
-    float acc[K];
+    float acc[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) acc[r] = a.w.gen_b[tid];
-    for (int k = 0; k < H; ++k) {
-      const float w = a.w.gen_wt[(long)k * V + tid];
+    for (int r = 0; r < KR; ++r) acc[r] = a.w.gen_b[tid];
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += 8) {
+      float wq[8];
 #pragma unroll
-      for (int r = 0; r < K; ++r) acc[r] = fmaf(w, sh[k][r], acc[r]);
+      for (int u = 0; u < 8; ++u) wq[u] = a.w.gen_wt[(long)(k0 + u) * V + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) acc[r] = fmaf(wq[u], sh[k0 + u][r], acc[r]);
     }
 #pragma unroll
-    for (int r = 0; r < K; ++r) slog[r][tid] = (tid == a.blank_id) ? -1e4f : acc[r];
+    for (int r = 0; r < KR; ++r) slog[r][tid] = (tid == a.blank_id) ? -1e4f : acc[r];
   }
   __syncthreads();
 }
@@ -354,7 +388,7 @@ __device__ __forceinline__ void block_argmax(float v, int idx, float* s_val, int
 __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
   constexpr int H = ATT_H, K = 1;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // batch_H[T][H] | proj_H[T][H]
-  __shared__ __attribute__((aligned(16))) float sh[H][ATT_KMAX], sctx[H][ATT_KMAX];
+  __shared__ __attribute__((aligned(16))) float sh[H][K], sctx[H][K];
   __shared__ float sph[K][H], salpha[K][64], slog[K][256];
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
@@ -370,7 +404,7 @@ __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
   int tok[K] = {a.sos_id};
   __syncthreads();
   for (int s = 0; s < a.steps; ++s) {
-    attention_cell_step<K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
+    attention_cell_step<K, 1>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
     float v = -INFINITY;
     int idx = 0x7fffffff;
     if (tid < V) {
@@ -386,56 +420,63 @@ __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void attn_beam_kernel(AttnArgs a) {
-  constexpr int H = ATT_H, K = ATT_KMAX;
-  extern __shared__ __attribute__((aligned(16))) float dyn[];
-  __shared__ __attribute__((aligned(16))) float sh[H][ATT_KMAX], sctx[H][ATT_KMAX];
-  __shared__ float sph[K][H], salpha[K][64], slog[K][256];
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void attn_beam_kernel(AttnArgs a) {
+  constexpr int H = ATT_H, K = ATT_KMAX, KR = NB * K;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // batch_H[NB][T][H] | proj_H[NB][T][H]
+  __shared__ __attribute__((aligned(16))) float sh[H][KR], sctx[H][KR];
+  __shared__ float sph[KR][H], salpha[KR][64], slog[KR][256];
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
-  __shared__ float s_score[K], s_lse[K], s_top[K];
-  __shared__ int s_tok[K], s_done[K], s_src[K], s_nxt[K];
-  const int b = blockIdx.x, tid = threadIdx.x, T = a.T, V = a.V, KB = a.K;
+  __shared__ float s_score[KR], s_lse[KR], s_top[KR];
+  __shared__ int s_tok[KR], s_done[KR], s_src[KR], s_nxt[KR];
+  const int b0 = blockIdx.x * NB, tid = threadIdx.x, T = a.T, V = a.V, KB = a.K;
   float* sH = dyn;
-  float* sP = dyn + T * H;
-  for (int i = tid; i < T * H; i += 256) {
-    sH[i] = a.batch_H[(long)b * T * H + i];
-    sP[i] = a.proj_H[(long)b * T * H + i];
+  float* sP = dyn + NB * T * H;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int b = min(b0 + nb, a.B - 1);  // a ragged last workgroup recomputes row B-1 and does not store it
+    for (int i = tid; i < T * H; i += 256) {
+      sH[nb * T * H + i] = a.batch_H[(long)b * T * H + i];
+      sP[nb * T * H + i] = a.proj_H[(long)b * T * H + i];
+    }
   }
-  float c[K];
+  float c[KR];
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
+  for (int r = 0; r < KR; ++r) {
     c[r] = 0.f;
     sh[tid][r] = 0.f;
   }
-  if (tid < K) {
-    s_score[tid] = tid == 0 ? 0.f : -INFINITY;
+  if (tid < KR) {
+    s_score[tid] = (tid % K) == 0 ? 0.f : -INFINITY;
     s_tok[tid] = a.sos_id;
     s_done[tid] = 0;
   }
   __syncthreads();
-  int fin = a.steps;
+  int fin[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) fin[nb] = a.steps;
   const float temp = fmaxf(a.temperature, 1e-6f);
   for (int s = 0; s < a.steps; ++s) {
-    int tok[K];
+    int tok[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) tok[r] = s_tok[r];
-    attention_cell_step<K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
+    for (int r = 0; r < KR; ++r) tok[r] = s_tok[r];
+    attention_cell_step<KR, K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
     // temperature (true f32 division, model.py:135-137), keep the scaled logits for the trace
     if (tid < V) {
 #pragma unroll
-      for (int r = 0; r < K; ++r) {
+      for (int r = 0; r < KR; ++r) {
         float v = slog[r][tid];
         if (a.temperature != 1.0f) v = v / temp;
         slog[r][tid] = v;
-        if (r < KB) a.logits_out[(((long)b * a.steps + s) * KB + r) * V + tid] = v;
+        const int b = b0 + r / K, rb = r % K;
+        if (rb < KB && b < a.B) a.logits_out[(((long)b * a.steps + s) * KB + rb) * V + tid] = v;
       }
     }
     __syncthreads();
-    // log_softmax per beam row: wave w handles rows w, w+4
+    // log_softmax per state row: one wave per row
     {
       const int lane = tid & 63, wv = tid >> 6;
-      for (int r = wv; r < KB; r += 4) {
+      for (int r = wv; r < KR; r += 4) {
         float m = -INFINITY;
         for (int v = lane; v < V; v += 64) m = fmaxf(m, slog[r][v]);
 #pragma unroll
@@ -449,11 +490,11 @@ __global__ __launch_bounds__(256) void attn_beam_kernel(AttnArgs a) {
     __syncthreads();
     // candidates: cand[r][v] = (score[r] + logp[r][v]) / lp ; finished beams: only EOS with logp 0
     const float lp = a.lp ? a.lp[s] : 1.0f;
-    float cv[K];
+    float cv[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
+    for (int r = 0; r < KR; ++r) {
       cv[r] = -INFINITY;
-      if (tid < V && r < KB) {
+      if (tid < V && (r % K) < KB) {
         float logp = slog[r][tid] - s_lse[r];  // log_softmax = x - (max + log(sum exp(x - max)))
         if (s_done[r]) logp = (tid == a.eos_id) ? 0.f : -INFINITY;
         float tot = s_score[r] + logp;
@@ -461,83 +502,99 @@ __global__ __launch_bounds__(256) void attn_beam_kernel(AttnArgs a) {
         cv[r] = tot;
       }
     }
-    // top-K by K rounds of block arg-max over the K*V candidates (flat index = r*V + v)
-    for (int kk = 0; kk < KB; ++kk) {
-      float bvv = -INFINITY;
-      int bii = 0x7fffffff;
+    // top-K per batch row by K rounds of block arg-max over its K*V candidates (flat index = beam*V + v)
 #pragma unroll
-      for (int r = 0; r < K; ++r) {
-        const int fi = r * V + tid;
-        if (tid < V && r < KB && (cv[r] > bvv || (cv[r] == bvv && fi < bii))) { bvv = cv[r]; bii = fi; }
-      }
-      if (!(tid < V)) bii = 0x7fffffff;
-      float wv_;
-      int wi_;
-      block_argmax(bvv, bii, s_val, s_idx, tid, wv_, wi_);
-      if (wi_ == 0x7fffffff) wi_ = 0;  // all candidates -inf/NaN: degenerate, pick index 0 like a fallback
-      if (tid == 0) {
-        s_top[kk] = wv_;
-        s_src[kk] = wi_ / V;
-        s_nxt[kk] = wi_ % V;
-      }
-      // remove the winner: NaN never wins a comparison again
-      if (tid < V) {
-        const int wr = wi_ / V, wc = wi_ - wr * V;
+    for (int nb = 0; nb < NB; ++nb) {
+      for (int kk = 0; kk < KB; ++kk) {
+        float bvv = -INFINITY;
+        int bii = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < K; ++r)
-          if (r == wr && tid == wc) cv[r] = __int_as_float(0x7fc00000);
+        for (int rb = 0; rb < K; ++rb) {
+          const int fi = rb * V + tid;
+          const float x = cv[nb * K + rb];
+          if (tid < V && rb < KB && (x > bvv || (x == bvv && fi < bii))) { bvv = x; bii = fi; }
+        }
+        float wv_;
+        int wi_;
+        block_argmax(bvv, bii, s_val, s_idx, tid, wv_, wi_);
+        if (wi_ == 0x7fffffff) wi_ = 0;  // every candidate NaN: degenerate input
+        if (tid == 0) {
+          s_top[nb * K + kk] = wv_;
+          s_src[nb * K + kk] = wi_ / V;
+          s_nxt[nb * K + kk] = wi_ % V;
+        }
+        // remove the winner: NaN never wins a comparison again
+        if (tid < V) {
+          const int wr = wi_ / V, wc = wi_ - wr * V;
+#pragma unroll
+          for (int rb = 0; rb < K; ++rb)
+            if (rb == wr && tid == wc) cv[nb * K + rb] = __int_as_float(0x7fc00000);
+        }
       }
-      __syncthreads();
     }
-    // reorder beam state by src
-    float cn[K], hn[K];
+    __syncthreads();
+    // reorder beam state by src (within each batch row)
+    float cn[KR], hn[KR];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-      const int src = r < KB ? s_src[r] : r;
+    for (int r = 0; r < KR; ++r) {
+      const int nb = r / K, rb = r % K;
+      const int src = rb < KB ? s_src[r] : rb;
       float cc = 0.f, hh = 0.f;
 #pragma unroll
       for (int q = 0; q < K; ++q) {
-        cc = (q == src) ? c[q] : cc;
-        hh = (q == src) ? sh[tid][q] : hh;
+        cc = (q == src) ? c[nb * K + q] : cc;
+        hh = (q == src) ? sh[tid][nb * K + q] : hh;
       }
       cn[r] = cc;
       hn[r] = hh;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
+    for (int r = 0; r < KR; ++r) {
       c[r] = cn[r];
       sh[tid][r] = hn[r];
     }
-    int alldone = 1;
-    int nd[K];
+    int nd[KR];
+    int alldone[NB];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-      nd[r] = r < KB ? (s_done[s_src[r]] | (s_nxt[r] == a.eos_id)) : 1;
-      alldone &= nd[r];
+    for (int nb = 0; nb < NB; ++nb) alldone[nb] = 1;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const int nb = r / K, rb = r % K;
+      nd[r] = rb < KB ? (s_done[nb * K + s_src[r]] | (s_nxt[r] == a.eos_id)) : 1;
+      alldone[nb] &= nd[r];
     }
     __syncthreads();
-    if (tid < KB) {
-      const long o = ((long)b * a.steps + s) * KB + tid;
-      a.back[o] = s_src[tid];
-      a.tokv[o] = s_nxt[tid];
-      s_score[tid] = a.lp ? s_top[tid] * lp : s_top[tid];  // f32 round trip of the reference (model.py:188-192)
-      s_tok[tid] = s_nxt[tid];
-      s_done[tid] = nd[tid];
+    if (tid < KR) {
+      const int nb = tid / K, rb = tid % K, b = b0 + nb;
+      if (rb < KB) {
+        if (b < a.B) {
+          const long o = ((long)b * a.steps + s) * KB + rb;
+          a.back[o] = s_src[tid];
+          a.tokv[o] = s_nxt[tid];
+        }
+        s_score[tid] = a.lp ? s_top[tid] * lp : s_top[tid];  // f32 round trip of the reference (model.py:188-192)
+        s_tok[tid] = s_nxt[tid];
+        s_done[tid] = nd[tid];
+      }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < NB && b0 + tid < a.B) {
       // best beam if the loop stopped after this step: argmax of the un-normalised sums, first maximum
       int best = 0;
-      float bs = s_score[0];
+      float bs = s_score[tid * K];
       for (int r = 1; r < KB; ++r)
-        if (s_score[r] > bs) { bs = s_score[r]; best = r; }
-      a.best_at[(long)b * a.steps + s] = best;
+        if (s_score[tid * K + r] > bs) { bs = s_score[tid * K + r]; best = r; }
+      a.best_at[(long)(b0 + tid) * a.steps + s] = best;
     }
-    if (alldone && fin == a.steps) fin = s + 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (alldone[nb] && fin[nb] == a.steps) fin[nb] = s + 1;
     __syncthreads();
   }
-  if (tid == 0) a.fin_step[b] = fin;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    if (tid == 0 && b0 + nb < a.B) a.fin_step[b0 + nb] = fin[nb];
 }
 
 // finalize: walk the back-pointers from (t_run-1, best_at[t_run-1]) and gather the path's logits
@@ -613,14 +670,24 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
   a.tokv = (int32_t*)p; p += (int64_t)B * steps * beam * 4;
   a.best_at = (int32_t*)p;
   a.fin_step = fin_step_out;
-  const size_t lds = (size_t)2 * T * ATT_H * sizeof(float);
+  // NB = 2 batch rows per workgroup when their encoder rows fit in LDS beside the 68 KB of state (T <= 20), else 1
+  int NB = 1;
+  {
+    const char* e = getenv("MSOCR_BEAM_NB");  // tuning aid; default chosen from measurements
+    if (e && e[0] == '2' && T <= 20 && B >= 2) NB = 2;
+  }
+  const size_t lds = (size_t)2 * NB * T * ATT_H * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_beam_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 20 * ATT_H * 4) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
-  MSOCR_LAUNCH(attn_beam_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+  if (NB == 2)
+    MSOCR_LAUNCH(attn_beam_kernel<2>, dim3((B + 1) / 2), dim3(256), lds, (hipStream_t)stream, a);
+  else
+    MSOCR_LAUNCH(attn_beam_kernel<1>, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
   return LAUNCH_OK();
 }
 
