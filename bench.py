@@ -79,6 +79,8 @@ def main():
     det = EAST(state_dict=esd, target_size=(W, H), device="cuda", precision=a.precision)
     rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
+    if rec is not None and os.environ.get("MSOCR_DEVICE_BATCH"):
+        rec.device_batch = int(os.environ["MSOCR_DEVICE_BATCH"])
     if pipe is not None and a.serialize_streams:
         pipe.serialize_streams = True
 
