@@ -71,6 +71,13 @@ def lib():
     """Load libmsocr.so (once).  Fails loudly: the product has no non-HIP path."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+            # the in-tree build product is missing (fresh checkout): compile it once, in-tree, for gfx950
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"])
+            except Exception as e:  # fall through to the loud failure below
+                print(f"[manuscript_ocr_amd] building libmsocr.so failed: {e}")
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -13,6 +13,7 @@
 //   detectors/_east/east.py:13-30,56-67 ; recognizers/_trba/model/seresnet31.py:37-45,81-89,129-155
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msocr.h"
 
@@ -78,8 +79,8 @@ __device__ __forceinline__ int swz(int row) {
   return (row / RPB) & (CPR - 1);
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2>
+__global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
   constexpr int EPC = 16 / ES;   // elements per chunk
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   };
   constexpr int NQ = CPR / 2;
   for (int kt = 0; kt < p.ktiles; ++kt) {
-    const int cur = kt & 1;
+    const int cur = STAGES == 1 ? 0 : (kt & 1);
     if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
@@ -225,7 +226,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
     }
-    if (kt + 1 < p.ktiles) store_tile(cur ^ 1);
+    if (STAGES == 1) {  // one LDS stage (3 workgroups per CU): everyone must be done reading before it is overwritten
+      __syncthreads();
+      if (kt + 1 < p.ktiles) store_tile(0);
+    } else if (kt + 1 < p.ktiles) {
+      store_tile(cur ^ 1);
+    }
     __syncthreads();
   }
 
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -301,8 +307,8 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.ktiles = p.KH * p.KW * p.cin_tiles;
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI = (BM / WM) * 32 * BN * 4;
-  constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN>;
+  constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -320,7 +326,10 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
   constexpr int ES = sizeof(T);
   // row bytes: 128 B when Cin allows (f32: BK 32, bf16: BK 64), else 64 B
   const bool wide = (p.Cin * ES) % 128 == 0;
+  static const int variant = getenv("MSOCR_CONV_VARIANT") ? atoi(getenv("MSOCR_CONV_VARIANT")) : 0;
   if (p.Cout % 128 == 0) {
+    if (wide && variant == 1) return launch_cfg<T, 128, 128, 128, 64, 64, 1>(p, s);
+    if (variant == 2 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1>(p, s);
     return wide ? launch_cfg<T, 128, 128, 128, 64, 64>(p, s) : launch_cfg<T, 128, 128, 64, 64, 64>(p, s);
   } else if (p.Cout % 64 == 0) {
     return wide ? launch_cfg<T, 128, 64, 128, 64, 32>(p, s) : launch_cfg<T, 128, 64, 64, 64, 32>(p, s);

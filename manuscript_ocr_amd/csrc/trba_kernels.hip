@@ -47,20 +47,56 @@ __device__ __forceinline__ float wave_sum(float v) {
 // --------------------------------------------------------------------------------------------- SE tail
 // One workgroup per sample: mean over HW (coalesced over channels), two tiny FCs, then
 // out = relu(x * gate + identity).  x is re-read from L2 for the last phase.
+// 4 channels per lane (16-byte f32 / 8-byte bf16 accesses); the 256 threads split into PG = 1024/C pixel groups whose
+// partial channel sums are combined through LDS in a fixed order (deterministic).
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 ld4<uint16_t>(const uint16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  f32x4 r = {bf2f((uint16_t)(v.x & 0xffff)), bf2f((uint16_t)(v.x >> 16)), bf2f((uint16_t)(v.y & 0xffff)), bf2f((uint16_t)(v.y >> 16))};
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v);
+template <>
+__device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <>
+__device__ __forceinline__ void st4<uint16_t>(uint16_t* p, f32x4 v) {
+  uint2 o;
+  o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ x, const T* __restrict__ idt, int HW, int C,
                                                            const float* __restrict__ w1, const float* __restrict__ w2,
                                                            float* __restrict__ gate_ws, T* __restrict__ out) {
-  extern __shared__ float sm[];  // mean[C] | hid[C/16] | gate[C]
-  float* mean = sm;
-  float* hid = sm + C;
-  float* gate = hid + C / 16;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // part[PG][C] | mean[C] | hid[C/16] | gate[C]
   const int n = blockIdx.x, tid = threadIdx.x;
+  const int C4 = C / 4, PG = 256 / C4;  // host guarantees C in {64,128,256,512,1024}: C4 divides 256
+  float* part = sm;
+  float* mean = sm + PG * C;
+  float* hid = mean + C;
+  float* gate = hid + C / 16;
   const T* xs = x + (long)n * HW * C;
+  const int cg = tid % C4, pg = tid / C4;
+  {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pg; p < HW; p += PG) {
+      const f32x4 v = ld4<T>(xs + (long)p * C + cg * 4);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(&part[pg * C + cg * 4]) = s;
+  }
+  __syncthreads();
   const float inv = 1.0f / (float)HW;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += ldf<T>(xs + (long)p * C + c);
+    for (int g = 0; g < PG; ++g) s += part[g * C + c];
     mean[c] = s * inv;
   }
   __syncthreads();
@@ -85,18 +121,21 @@ __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ 
   __syncthreads();
   const T* is = idt + (long)n * HW * C;
   T* os = out + (long)n * HW * C;
-  const long tot = (long)HW * C;
-  for (long i = tid; i < tot; i += 256) {
-    const int c = (int)(i % C);
-    const float v = ldf<T>(xs + i) * gate[c] + ldf<T>(is + i);
-    stf<T>(os + i, fmaxf(v, 0.f));
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[cg * 4]);
+  for (int p = pg; p < HW; p += PG) {
+    const long o = (long)p * C + cg * 4;
+    const f32x4 v = ld4<T>(xs + o), r = ld4<T>(is + o);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = fmaxf(v[e] * g4[e] + r[e], 0.f);
+    st4<T>(os + o, y);
   }
 }
 
 extern "C" int msocr_se_residual(const void* x, const void* identity, int N, int HW, int C, int dtype, const float* w1, const float* w2,
                                  float* gate_ws, void* out, void* stream) {
-  if (!x || !identity || !w1 || !w2 || !gate_ws || !out || N <= 0 || HW <= 0 || C <= 0 || C % 16) return MSOCR_E_ARG;
-  const size_t lds = (size_t)(2 * C + C / 16) * sizeof(float);
+  if (!x || !identity || !w1 || !w2 || !gate_ws || !out || N <= 0 || HW <= 0 || C < 64 || C > 1024 || (C & (C - 1))) return MSOCR_E_ARG;
+  const size_t lds = (size_t)((1024 / C) * C + 2 * C + C / 16) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MSOCR_F32)
     MSOCR_LAUNCH(se_residual_kernel<float>, dim3(N), dim3(256), lds, s, (const float*)x, (const float*)identity, HW, C, w1, w2, gate_ws,
