@@ -200,3 +200,26 @@ def test_empty_and_ragged_inputs(gpu):
     assert len(one.blocks[0].words) == 1 and one.blocks[0].words[0].text is None
     two = pipe.predict_batch([pages[0]], _maps_override=(score, geo))[0]
     assert two.blocks[0].words[0].text is not None and 0.0 <= two.blocks[0].words[0].recognition_confidence <= 1.0
+
+
+def test_square_target_size_resize_and_scale_back(gpu):
+    """Reference default geometry (infer.py:304,134-147): the page is resized to target_size x target_size ignoring
+    aspect ratio, boxes are scaled back by (orig_w/T, orig_h/T).  Device resize == oracle's cv2 restatement, and the
+    final boxes on injected maps == the oracle's post-processing, bit for bit."""
+    from manuscript_ocr_amd import ops, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from oracle import east_model as oem
+    from oracle import east_post as P
+    from oracle import imgproc
+    from oracle import lanms as L
+    T = 256
+    page, _ = synth.synth_page(9, 300, 420)
+    det = EAST(state_dict=oem.synth_east_state_dict(), target_size=T, device="cuda")
+    got_resized = ops.resize_linear_u8(torch.from_numpy(page[None]).cuda(), T, T)[0].cpu().numpy()
+    assert np.array_equal(got_resized, imgproc.resize_linear_u8(page, T, T))
+    rects = synth.synth_layout(9, T, T, line_pitch=40, word_h=30, margin=10)
+    score, geo = synth.synth_maps(rects, (T, T), (T // 4, T // 4), 9)
+    res = det.predict_batch([page], _maps_override=(torch.from_numpy(score)[None].cuda(), torch.from_numpy(geo)[None].cuda()))[0]
+    exp = P.east_postprocess(score, geo, (300, 420), T, L.locality_aware_nms)
+    got = np.array([[c for pt in w.polygon for c in pt] + [w.detection_confidence] for w in res["page"].blocks[0].words], dtype=np.float32)
+    assert len(exp) >= 3 and got.shape == exp.shape and np.array_equal(got, exp)
