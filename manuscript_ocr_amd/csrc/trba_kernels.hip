@@ -182,7 +182,7 @@ extern "C" int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int
 // four gates for RB batch rows; h_{t-1} of the RB rows sits in LDS as [k][r] so one
 // ds_read_b128 pair broadcasts the 8 row values of column k; W_hh^T rows stream from L2,
 // coalesced over j.  xproj already holds x W_ih^T + b_ih + b_hh.
-#define LSTM_RB 8
+#define LSTM_RB 4
 __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t, int B, int T,
                                                       float* __restrict__ hcat) {
   constexpr int H = 256, G = 4 * H, RB = LSTM_RB;
@@ -215,9 +215,12 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
       for (int u = 0; u < 8; ++u) wq[u] = *reinterpret_cast<const f32x4*>(&wt[((long)(k0 + u) * H + j) * 4]);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[cur][k0 + u][0]);
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[cur][k0 + u][4]);
-        const float hv[RB] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        float hv[RB];
+#pragma unroll
+        for (int r4 = 0; r4 < RB; r4 += 4) {
+          const f32x4 hq = *reinterpret_cast<const f32x4*>(&hs[cur][k0 + u][r4]);
+          hv[r4] = hq[0]; hv[r4 + 1] = hq[1]; hv[r4 + 2] = hq[2]; hv[r4 + 3] = hq[3];
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll

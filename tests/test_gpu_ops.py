@@ -253,3 +253,35 @@ def test_lanms_speculative_scan_long_and_short_runs(ops, seed, n_base, max_run):
     nb = int(nbox.cpu()[0])
     assert nb == len(exp)
     assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+def test_decode_lanms_many_pages_stress(ops):
+    """12 pages in one launch (grid-of-words maps with sprinkled noise, different layouts): every page's decode and
+    LANMS output equals the oracle bit for bit; run twice to catch nondeterminism."""
+    from manuscript_ocr_amd import synth
+    from oracle import east_post as P
+    from oracle import lanms as L
+    H, W = 768, 1024
+    rng = np.random.default_rng(123)
+    scores, geos = [], []
+    for n in range(12):
+        rects = synth.synth_layout(900 + n, H, W, line_pitch=int(rng.integers(30, 60)), word_h=int(rng.integers(16, 28)))
+        s, g_ = synth.synth_maps(rects, (H, W), (H // 4, W // 4), 900 + n)
+        ys, xs = rng.integers(0, H // 4, 150), rng.integers(0, W // 4, 150)
+        s[ys, xs] = rng.uniform(0.5, 0.99, 150).astype(np.float32)  # isolated junk candidates
+        scores.append(s), geos.append(g_)
+    score = torch.from_numpy(np.stack(scores)).cuda()
+    geo = torch.from_numpy(np.stack(geos)).cuda()
+    exp = []
+    for n in range(12):
+        dec = P.decode_quads_from_maps(scores[n], geos[n], 0.6, 4.0, 2)
+        exp.append((dec, L.locality_aware_nms(dec, 0.2)))
+    for _ in range(2):
+        cand, cnt = ops.east_decode(score, geo, 0.6, 4.0, 2, 16384)
+        boxes, nbox = ops.east_lanms(cand, cnt, 0.2)
+        cnt_h, nbox_h = cnt.cpu().numpy(), nbox.cpu().numpy()
+        for n in range(12):
+            dec, out = exp[n]
+            assert cnt_h[n] == len(dec) and nbox_h[n] == len(out), (n, cnt_h[n], len(dec), nbox_h[n], len(out))
+            assert np.array_equal(cand[n, :cnt_h[n]].cpu().numpy().view(np.uint32), dec.view(np.uint32))
+            assert np.array_equal(boxes[n, :nbox_h[n]].cpu().numpy().view(np.uint32), out.view(np.uint32)), n

@@ -16,3 +16,16 @@ for B in (960, 2048):
         for _ in range(3): fn()
         e1.record(); torch.cuda.synchronize()
         print(f"B={B} {name}: {e0.elapsed_time(e1)/3:.3f} ms  NB={os.environ.get('MSOCR_BEAM_NB','auto')}")
+
+# BiLSTM recurrence
+from manuscript_ocr_amd import ops
+for B in (960,):
+    H, T = 256, 13
+    xproj = torch.randn(B * T, 8 * H, device="cuda")
+    whh = torch.randn(2, H, H, 4, device="cuda") * 0.05
+    ops.bilstm_recurrent(xproj, whh, B, T, H); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.bilstm_recurrent(xproj, whh, B, T, H)
+    e1.record(); torch.cuda.synchronize()
+    print(f"B={B} bilstm: {e0.elapsed_time(e1)/5:.3f} ms")
