@@ -34,8 +34,8 @@ TRBA_CFG = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pipeline", choices=["east", "pipeline"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="conv storage/MFMA input type; fp32 = parity mode (text identical to the CPU reference)")

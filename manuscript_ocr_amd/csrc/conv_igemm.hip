@@ -221,10 +221,22 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
         read_frags(sa, sb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (sizeof(T) == 4) {
+        // k-element outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[q & 1][i][e]), __uint_as_float(fb[q & 1][j][e]),
+                                                               acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+      }
     }
     if (STAGES == 1) {  // one LDS stage (3 workgroups per CU): everyone must be done reading before it is overwritten
       __syncthreads();
