@@ -35,7 +35,7 @@ def gather_records(local_records: List[Any], device: torch.device) -> List[Any]:
     import torch.distributed as dist
 
     payload = np.frombuffer(json.dumps(local_records, ensure_ascii=False).encode("utf-8"), dtype=np.uint8)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return json.loads(payload.tobytes().decode("utf-8"))
     world = dist.get_world_size()
     n_local = torch.tensor([payload.size], dtype=torch.int64, device=device)

@@ -285,3 +285,21 @@ def test_decode_lanms_many_pages_stress(ops):
             assert cnt_h[n] == len(dec) and nbox_h[n] == len(out), (n, cnt_h[n], len(dec), nbox_h[n], len(out))
             assert np.array_equal(cand[n, :cnt_h[n]].cpu().numpy().view(np.uint32), dec.view(np.uint32))
             assert np.array_equal(boxes[n, :nbox_h[n]].cpu().numpy().view(np.uint32), out.view(np.uint32)), n
+
+
+def test_lanms_many_unmerged_polygons_general_nms_path(ops):
+    """> 4096 merged polygons (nothing merges in phase 1): exercises the NMS path that keeps polygons in global
+    memory instead of registers; equals the oracle bit for bit."""
+    from oracle import lanms as L
+    rng = np.random.default_rng(77)
+    n = 4300
+    cx, cy = rng.uniform(50, 6000, n), rng.uniform(50, 6000, n)
+    w, h = rng.uniform(10, 60, n), rng.uniform(6, 20, n)
+    inp = np.stack([cx - w, cy - h, cx + w, cy - h, cx + w, cy + h, cx - w, cy + h, rng.uniform(0.1, 1.0, n)], axis=1).astype(np.float32)
+    exp, nm = L.locality_aware_nms(inp, 0.2, return_merged_count=True)
+    assert nm > 4096
+    cand = torch.from_numpy(inp).cuda()[None].contiguous()
+    boxes, nbox = ops.east_lanms(cand, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.2)
+    nb = int(nbox.cpu()[0])
+    assert nb == len(exp)
+    assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
