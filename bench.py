@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap-steps", action="store_true", help="do not enqueue step i+1's detector work before collecting step i")
     ap.add_argument("--sub-batches", type=int, default=0, help="sub-batch groups pipelined on separate streams (0 = auto)")
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the sub-batch pipeline on ONE stream (no cross-stream kernel overlap): per-kernel profiling mode")
@@ -94,23 +95,39 @@ def main():
     pages_dev = torch.from_numpy(np.stack(pages)).cuda()
     maps_dev = (torch.from_numpy(np.stack(scores)).cuda(), torch.from_numpy(np.stack(geos)).cuda())
 
+    def submit():
+        return pipe.submit_batch(pages, pages_dev=pages_dev, sub_batches=a.sub_batches, _maps_override=maps_dev)
+
     def step():
         if pipe is not None:
-            return pipe.predict_batch(pages, pages_dev=pages_dev, sub_batches=a.sub_batches, _maps_override=maps_dev)
+            return pipe.collect_batch(submit())
         return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
+
+    def run_steps(k):
+        """k steps; with the pipeline workload the detector work of step i+1 is enqueued (on the other stream set)
+        before step i is collected, so the device never drains between steps.  All work of the k steps is inside."""
+        if pipe is None or a.serialize_streams or a.no_overlap_steps:
+            out_ = None
+            for _ in range(k):
+                out_ = step()
+            return out_
+        h, out_ = submit(), None
+        for i in range(k):
+            h_next = submit() if i + 1 < k else None
+            out_ = pipe.collect_batch(h)
+            h = h_next
+        return out_
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     out = None
-    for _ in range(a.warmup):
-        out = step()
+    out = run_steps(a.warmup) if a.warmup else None
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
+    out = run_steps(a.steps)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -171,8 +188,7 @@ def main():
             ref = torch.cuda.Event(enable_timing=True)
             ref.record()
             ops.PROFILE = []
-            for _ in range(a.steps):
-                step()
+            run_steps(a.steps)
             torch.cuda.synchronize()
             prof, ops.PROFILE = ops.PROFILE, None
             if pipe is not None:

@@ -144,15 +144,23 @@ class Pipeline:
         confidences still follow the reference's per-page / per-`batch_size` chunking.  The batch is processed as
         `sub_batches` groups on separate HIP streams in a software pipeline, so the host stages of one group (box
         filters, reading order, crop descriptors) overlap the device work of the others.
-        `pages_dev`: optional [N,H,W,3] u8 device tensor already holding `images` (benchmarks: inputs resident in HBM)."""
+        `pages_dev`: optional [N,H,W,3] u8 device tensor already holding `images` (benchmarks: inputs resident in HBM).
+        = collect_batch(submit_batch(...)); call the two halves yourself to overlap consecutive batches."""
         native = isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA)
         if not native:
             return [self.predict(im, recognize_text=recognize_text, profile=profile) for im in images]
+        return self.collect_batch(self.submit_batch(images, recognize_text, profile, pages_dev, sub_batches, _maps_override))
+
+    def submit_batch(self, images, recognize_text: bool = True, profile: bool = False, pages_dev=None, sub_batches: int = 0,
+                     _maps_override=None):
+        """Stage 1 of `predict_batch`: upload (if needed) and enqueue every group's detector work; returns a handle
+        without synchronising.  Consecutive submits alternate between two sets of streams, so the detector work of
+        batch i+1 can be enqueued before `collect_batch` of batch i and fills the device while batch i drains."""
+        if not (isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA)):
+            raise TypeError("submit_batch/collect_batch need this package's EAST and TRBA plugins")
         import torch
 
-        from . import ops
-        det, rec = self.detector, self.recognizer
-        tm = {"detect_wait+tail": 0.0, "order": 0.0, "crop+enqueue": 0.0, "recognize_wait": 0.0, "assign": 0.0}
+        det = self.detector
         arrays = [read_image(im) for im in images]
         if len({a.shape for a in arrays}) != 1:
             raise ValueError("predict_batch needs equally sized pages")
@@ -166,11 +174,13 @@ class Pipeline:
         if getattr(self, "serialize_streams", False):  # profiling aid: same launches, no cross-stream kernel overlap
             streams = [main] * nsub
         else:
-            if not hasattr(self, "_streams") or len(self._streams) < nsub:
-                self._streams = [torch.cuda.Stream() for _ in range(nsub)]
-            streams = self._streams[:nsub]
-        H, W = arrays[0].shape[:2]
-        # stage 1: enqueue every group's detector work (async)
+            if not hasattr(self, "_stream_sets"):
+                self._stream_sets, self._set_idx = [[], []], 0
+            self._set_idx ^= 1
+            pool = self._stream_sets[self._set_idx]
+            while len(pool) < nsub:
+                pool.append(torch.cuda.Stream())
+            streams = pool[:nsub]
         det_handles = []
         for (lo, hi), st in zip(bounds, streams):
             if st is not main:
@@ -178,9 +188,23 @@ class Pipeline:
             with torch.cuda.stream(st):
                 mo = None if _maps_override is None else (_maps_override[0][lo:hi], _maps_override[1][lo:hi])
                 det_handles.append(det.detect_start(pages_dev[lo:hi], mo))
+        return {"arrays": arrays, "pages_dev": pages_dev, "bounds": bounds, "streams": streams, "main": main,
+                "det_handles": det_handles, "recognize_text": recognize_text, "profile": profile}
+
+    def collect_batch(self, h):
+        """Stages 2-3 of `predict_batch` for a handle from `submit_batch` -> list of Pages."""
+        import torch
+
+        from . import ops
+        det, rec = self.detector, self.recognizer
+        arrays, pages_dev, bounds, streams, main = h["arrays"], h["pages_dev"], h["bounds"], h["streams"], h["main"]
+        recognize_text, profile = h["recognize_text"], h["profile"]
+        tm = {"detect_wait+tail": 0.0, "order": 0.0, "crop+enqueue": 0.0, "recognize_wait": 0.0, "assign": 0.0}
+        N = len(arrays)
+        H, W = arrays[0].shape[:2]
         # stage 2: per group — wait for its boxes, host tail + reading order, enqueue crops + recogniser (async)
         pages, groups = [None] * N, []
-        for (lo, hi), st, dh in zip(bounds, streams, det_handles):
+        for (lo, hi), st, dh in zip(bounds, streams, h["det_handles"]):
             with torch.cuda.stream(st):
                 t0 = time.perf_counter()
                 res = det.detect_finish(dh, arrays[lo:hi], profile=profile)
