@@ -462,19 +462,33 @@ __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
   }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void attn_beam_kernel(AttnArgs a) {
+// HB = number of 256-thread halves per workgroup.  With HB = 2 two batch rows share one workgroup: both halves run
+// the same instruction stream between the same barriers, so the second half's weight loads hit the lines the first
+// half just pulled into the CU's L1 — the L2 -> L1 weight stream that bounds this kernel is paid once for two rows,
+// at unchanged registers per thread and waves per CU.
+template <int NB, int HB>
+__global__ __launch_bounds__(256 * HB, (NB == 1 && HB == 1) ? 2 : 1) void attn_beam_kernel(AttnArgs a) {
   constexpr int H = ATT_H, K = ATT_KMAX, KR = NB * K;
-  extern __shared__ __attribute__((aligned(16))) float dyn[];  // batch_H[NB][T][H] | proj_H[NB][T][H]
-  __shared__ __attribute__((aligned(16))) float sh[H][KR], sctx[H][KR];
-  __shared__ float sph[KR][H], salpha[KR][64], slog[KR][256];
-  __shared__ float s_val[4];
-  __shared__ int s_idx[4];
-  __shared__ float s_score[KR], s_lse[KR], s_top[KR];
-  __shared__ int s_tok[KR], s_done[KR], s_src[KR], s_nxt[KR];
-  const int b0 = blockIdx.x * NB, tid = threadIdx.x, T = a.T, V = a.V, KB = a.K;
-  float* sH = dyn;
-  float* sP = dyn + NB * T * H;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // per half: batch_H[NB][T][H] | proj_H[NB][T][H]
+  __shared__ __attribute__((aligned(16))) float sh_[HB][H][KR], sctx_[HB][H][KR];
+  __shared__ float sph_[HB][KR][H], salpha_[HB][KR][64], slog_[HB][KR][256];
+  __shared__ float s_val_[HB][4];
+  __shared__ int s_idx_[HB][4];
+  __shared__ float s_score_[HB][KR], s_lse_[HB][KR], s_top_[HB][KR];
+  __shared__ int s_tok_[HB][KR], s_done_[HB][KR], s_src_[HB][KR], s_nxt_[HB][KR];
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  float (*sh)[KR] = sh_[half];
+  float (*sctx)[KR] = sctx_[half];
+  float (*sph)[H] = sph_[half];
+  float (*salpha)[64] = salpha_[half];
+  float (*slog)[256] = slog_[half];
+  float* s_val = s_val_[half];
+  int* s_idx = s_idx_[half];
+  float *s_score = s_score_[half], *s_lse = s_lse_[half], *s_top = s_top_[half];
+  int *s_tok = s_tok_[half], *s_done = s_done_[half], *s_src = s_src_[half], *s_nxt = s_nxt_[half];
+  const int b0 = (blockIdx.x * HB + half) * NB, T = a.T, V = a.V, KB = a.K;
+  float* sH = dyn + half * (2 * NB * T * H);
+  float* sP = sH + NB * T * H;
   for (int nb = 0; nb < NB; ++nb) {
     const int b = min(b0 + nb, a.B - 1);  // a ragged last workgroup recomputes row B-1 and does not store it
     for (int i = tid; i < T * H; i += 256) {
@@ -713,23 +727,25 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
   a.best_at = (int32_t*)p;
   a.fin_step = fin_step_out;
   // NB = 2 batch rows per workgroup when their encoder rows fit in LDS beside the 68 KB of state (T <= 20), else 1
-  int NB = 1;
-  {
-    const char* e = getenv("MSOCR_BEAM_NB");  // tuning aid; default chosen from measurements
-    if (e && e[0] == '2' && T <= 20 && B >= 2) NB = 2;
+  // two batch rows per workgroup (two 256-thread halves sharing the weight stream through L1) when both rows' encoder
+  // tiles fit in LDS beside 2 x 34 KB of state (T <= 20); MSOCR_BEAM_HB=1 forces one row per workgroup
+  int HB = 1;  // measured: two rows per workgroup (MSOCR_BEAM_HB=2) runs at the same speed (6.6 ms per 960 rows), so the
+  {            // kernel is bound by per-wave issue/latency, not by the L2 -> L1 weight stream; one row stays the default
+    const char* e = getenv("MSOCR_BEAM_HB");
+    if (e && e[0] == '2' && T <= 20 && B >= 2) HB = 2;
   }
-  const size_t lds = (size_t)2 * NB * T * ATT_H * sizeof(float);
+  const size_t lds = (size_t)2 * HB * T * ATT_H * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_beam_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_beam_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 20 * ATT_H * 4) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_beam_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 20 * ATT_H * 4) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
-  if (NB == 2)
-    MSOCR_LAUNCH(attn_beam_kernel<2>, dim3((B + 1) / 2), dim3(256), lds, (hipStream_t)stream, a);
+  if (HB == 2)
+    MSOCR_LAUNCH((attn_beam_kernel<1, 2>), dim3((B + 1) / 2), dim3(512), lds, (hipStream_t)stream, a);
   else
-    MSOCR_LAUNCH(attn_beam_kernel<1>, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+    MSOCR_LAUNCH((attn_beam_kernel<1, 1>), dim3(B), dim3(256), lds, (hipStream_t)stream, a);
   return LAUNCH_OK();
 }
 
