@@ -143,3 +143,55 @@ def test_gather_records_world2_gloo(tmp_path):
     recs = json.loads(line[len("RESULT"):])
     assert [r["page"] for r in recs] == list(range(7))
     assert recs[5]["text"] == "стр5 — ok"
+
+
+def test_vectorised_glue_equals_literal_restatement_on_random_boxes():
+    """The host fast paths (vectorised resolve_intersections, running-sum line grouping, dict re-match) against the
+    oracle's literal restatement of the reference loops, on random overlapping boxes incl. duplicates."""
+    from manuscript_ocr_amd.detectors._east import utils as U
+    from oracle import pipeline_glue as G
+    rng = np.random.default_rng(0)
+    for trial in range(25):
+        n = int(rng.integers(1, 90))
+        boxes = []
+        for _ in range(n):
+            x0, y0 = rng.integers(0, 400, 2)
+            w, h = rng.integers(3, 120), rng.integers(3, 40)
+            boxes.append(tuple(np.int32(v) for v in (x0, y0, x0 + w, y0 + h)))
+        if n > 3:
+            boxes[1] = boxes[0]  # duplicate AABBs collapse in the reference's dict mapping
+        as_int = lambda bs: [tuple(int(v) for v in b) for b in bs]
+        assert as_int(U.resolve_intersections(boxes)) == as_int(G.resolve_intersections(boxes))
+        assert as_int(U.sort_boxes_reading_order(boxes)) == as_int(G.sort_boxes_reading_order(boxes))
+        assert as_int(U.sort_boxes_reading_order_with_resolutions(boxes)) == as_int(G.sort_boxes_reading_order_with_resolutions(boxes))
+
+
+def test_pipeline_order_boxes_equals_oracle_order_and_crop():
+    """Pipeline._order_boxes (+ crop descriptors) vs the oracle's literal _pipeline.py:102-137 on random word layouts."""
+    from manuscript_ocr_amd import Pipeline, ops, synth
+    from manuscript_ocr_amd.detectors._types import Block, Page, Word
+    from oracle import pipeline_glue as G
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(600, 900, 3), dtype=np.uint8)
+    pipe = Pipeline(detector=object(), recognizer=object(), min_text_size=5)
+    for seed in range(6):
+        rects = synth.synth_layout(seed, 600, 900)
+        rects = rects[rng.permutation(len(rects))]
+        polys = []
+        for x0, y0, x1, y1 in rects:
+            j = rng.uniform(-3, 3, 8)
+            polys.append([[x0 + j[0], y0 + j[1]], [x1 + j[2], y0 + j[3]], [x1 + j[4], y1 + j[5]], [x0 + j[6], y1 + j[7]]])
+        polys.append([[10.0, 10.0], [12.5, 10.0], [12.5, 13.0], [10.0, 13.0]])  # below min_text_size
+        polys.append([[-20.0, -5.0], [40.0, -5.0], [40.0, 30.0], [-20.0, 30.0]])  # clamped at the border
+        polys = [[[float(np.float32(c)) for c in pt] for pt in q] for q in polys]
+        order, kept, crops = G.order_and_crop(polys, img, 5)
+        page = Page(blocks=[Block(words=[Word(polygon=q, detection_confidence=0.5) for q in polys])])
+        before = list(page.blocks[0].words)
+        words, boxes = pipe._order_boxes(page)
+        assert [before.index(w) for w in page.blocks[0].words] == order
+        assert [page.blocks[0].words.index(w) for w in words] == kept
+        desc, keep = ops.crop_descriptors(boxes, [0] * len(boxes), img.shape[:2], 32, 100)
+        assert keep.all() and len(desc) == len(crops)
+        for d, c in zip(desc, crops):
+            assert (d[4] - d[2], d[3] - d[1]) == c.shape[:2]
+            assert np.array_equal(img[d[2]:d[4], d[1]:d[3]], c)
