@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 TRBA_CFG = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+TIE_TOL = 5e-3  # first-step logit gap (|logit| ~ 5) treated as a tie between two f32 implementations (tests/conftest.py)
 
 
 def parse():
@@ -70,13 +71,11 @@ def main():
     from manuscript_ocr_amd.dist import gather_records, page_records
     from manuscript_ocr_amd.recognizers import TRBA
     from manuscript_ocr_amd.recognizers._trba.net import trba_cnn_macs
-    from oracle import east_model as oem  # synthetic-weight recipes shared with the CPU baseline
-    from oracle import trba_model as otm
 
     H, W = a.height, a.width
     NP = a.pages or (16 if a.workload == "pipeline" else 8)
-    esd = oem.synth_east_state_dict(seed=20260128)
-    tsd = otm.synth_trba_state_dict(194, 256, seed=20260128)
+    esd = synth.east_state_dict(seed=20260128)
+    tsd = synth.trba_state_dict_confident(194, 256, seed=20260128)
     det = EAST(state_dict=esd, target_size=(W, H), device="cuda", precision=a.precision)
     rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
@@ -239,7 +238,7 @@ def main():
                 a_[2] += f
             with open(os.environ["MSOCR_DUMP_CONV"], "w") as fh:
                 for tag, (cnt, m, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
+                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} {tag[3]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out)
@@ -281,7 +280,7 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     itos, _ = otm.load_charset(os.path.join(ROOT, "manuscript_ocr_amd", "recognizers", "_trba", "configs", "charset.txt"))
     L.lib()
     n, t0 = 0, time.perf_counter()
-    edits = chars = mism = 0
+    edits = chars = mism = n_words = n_diff = n_tie = 0
     with torch.no_grad():
         for pi, (pg, s, g) in enumerate(zip(pages, scores, geos)):
             net(torch.from_numpy(imgproc.east_preprocess(pg, W, H)))
@@ -289,17 +288,23 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
             if workload == "pipeline":
                 polys = [q[:8].reshape(4, 2).tolist() for q in quads]
                 order, kept, crops = G.order_and_crop(polys, pg, 5)
-                texts = []
+                res = []
                 for c0 in range(0, len(crops), 32):
                     x = torch.from_numpy(np.stack([imgproc.trba_preprocess(c, 32, 100) for c in crops[c0:c0 + 32]]))
                     lg, ids = tnet(x, max_len=25, mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
-                    texts += [r["text"] for r in otm.texts_and_confidences(lg, ids, itos, 0, 2, None)]
+                    res += otm.texts_and_confidences(lg, ids, itos, 0, 2, None)
                 gw = [w for w in gpu_pages[pi].blocks[0].words]
                 gtexts = [gw[pos].text for pos in kept] if len(gw) == len(order) else []
                 mism += int(len(gw) != len(order))
-                for ref_t, hyp in zip(texts, gtexts):
-                    edits += _lev(ref_t, hyp or "")
+                for r, hyp in zip(res, gtexts):
+                    ref_t, hyp = r["text"], hyp or ""
+                    edits += _lev(ref_t, hyp)
                     chars += max(len(ref_t), 1)
+                    n_words += 1
+                    if ref_t != hyp:
+                        # a word may differ only where the CPU path's own first-character arg-max is a rounding-level tie
+                        n_diff += 1
+                        n_tie += int(hyp[:1] != ref_t[:1] and otm.first_token_margin(r["logits0"], itos, 2, hyp, ref_t) < TIE_TOL)
             n += 1
             if time.perf_counter() - t0 > budget_s:
                 break
@@ -312,6 +317,9 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
         "sample": f"{n} page(s) @ {W}x{H} of the same synthetic workload: oracle torch-CPU fp32 EAST forward + C LANMS + NumPy "
                   f"filters" + (" + reading order + crops + torch-CPU TRBA beam-8" if workload == "pipeline" else "") + f" ({el:.1f} s)",
         "cer_gpu_vs_cpu": (edits / chars) if chars else None,
+        "words_compared": n_words,
+        "words_differing": n_diff,
+        "words_differing_at_cpu_near_tie": n_tie,  # first-character margin < TIE_TOL in the CPU path's own logits
         "box_count_mismatch_pages": mism,
     }
 

@@ -54,6 +54,19 @@ typedef struct msocr_conv_desc {
 int msocr_conv2d(const msocr_conv_desc* d, const void* in, const void* weight, const float* bias,
                  const void* residual, void* out, void* stream);
 
+/* The same convolution for KH=KW=3, stride 1, pad 1, MSOCR_F32, as Winograd F(2x2,3x3): input transform (HBM-bound) ->
+ * 16 GEMMs [tiles x Cin] x [Cin x Cout] in one MFMA launch -> output transform + bias/residual/ReLU (HBM-bound).
+ * 2.25x fewer matrix FLOPs than the direct form; all arithmetic f32 (differs from msocr_conv2d by rounding order only).
+ * u_weight = [16][Cout][Cin] f32 on the DEVICE, produced by msocr_winograd_weights_host (a HOST function: both of
+ * its pointers are host memory; evaluates G g G^T in f64, rounds once) from the BatchNorm-folded [Cout][3][3][Cin]
+ * weight.  workspace: msocr_conv3x3_winograd_workspace_bytes(d) bytes, 16-B aligned (-1 = shape not supported:
+ * Cin % 16, Cout % 32).  Same reference code as msocr_conv2d (every 3x3/1/1 conv of SE-ResNet31, ResNet-50 and the
+ * EAST decoder). */
+int64_t msocr_conv3x3_winograd_workspace_bytes(const msocr_conv_desc* d);
+int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                           const void* residual, void* out, void* workspace, void* stream);
+int msocr_winograd_weights_host(const float* w_khwc_host, int Cout, int Cin, float* u_out_host);
+
 /* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->cpad (4 or 8) inside a zero canvas
  * out[N][Hp][Wp][cpad], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
  *   mode 0: EAST ToTensor+Normalize, detectors/_east/infer.py:127-132,305  -> (x/255 - .5)/.5

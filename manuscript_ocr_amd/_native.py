@@ -36,6 +36,9 @@ class AttnWeights(ctypes.Structure):
 
 _SIGS = {
     "msocr_conv2d": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "msocr_conv3x3_winograd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_winograd_weights_host": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "internal.h"
 #include "msocr.h"
 
 // Clear any stale (sticky) HIP error left by earlier runtime calls of the host process before a launch,
@@ -43,6 +44,8 @@ struct ConvParams {
   long out_ld, res_ld;
   int relu, has_res;
   int tilesM, tilesN;
+  int nbatch;           // independent problems of identical shape in one launch (Winograd: the 16 transform points)
+  long bsA, bsW, bsO;   // element strides between consecutive problems (input, weight, output)
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -103,14 +106,20 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 
   // XCD-aware tile mapping: blocks b, b+8, ... share an XCD/L2 -> give each XCD a contiguous
   // range of logical tiles (all N-tiles of neighbouring M-tiles: shared A rows + 3x3 halos).
-  const int nblk = p.tilesM * p.tilesN;
+  const int nblk1 = p.tilesM * p.tilesN;
+  const int nblk = nblk1 * p.nbatch;
   int bid = blockIdx.x;
   {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
+  const int batch = bid / nblk1;
+  bid -= batch * nblk1;
   const int tile_n = bid % p.tilesN;
   const int tile_m = bid / p.tilesN;
+  const char* const g_in = p.in + (long)batch * p.bsA * ES;
+  const char* const g_w = p.w + (long)batch * p.bsW * ES;
+  char* const g_out = p.out + (long)batch * p.bsO * ES;
 
   // ---- per-thread staging coordinates (fixed over the K loop) ----
   const int chunk = tid % CPR;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
     const int co = tile_n * BN + row0 + j * RPP;
-    b_ptr[j] = p.w + ((long)co * p.Ktot + chunk * EPC) * ES;
+    b_ptr[j] = g_w + ((long)co * p.Ktot + chunk * EPC) * ES;
   }
 
   u32x4 ra[A_IT], rb[B_IT];
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       // branch-free: out-of-image taps read the (always valid) first 16 bytes of the tensor and are masked to zero
       const long off = ok ? (a_base[i] + koff) : 0;
-      ra[i] = *reinterpret_cast<const u32x4*>(p.in + off * ES);
+      ra[i] = *reinterpret_cast<const u32x4*>(g_in + off * ES);
       a_ok[i] = ok ? 0xffffffffu : 0u;  // applied when the tile is written to LDS: the load itself stays in flight
     }
 #pragma unroll
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
       }
-      *reinterpret_cast<u32x4*>(p.out + (m * p.out_ld + co) * ES) = o;
+      *reinterpret_cast<u32x4*>(g_out + (m * p.out_ld + co) * ES) = o;
     }
   }
 }
@@ -327,7 +336,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
       return MSOCR_E_LAUNCH;
     attr_set = true;
   }
-  const long nblk = (long)p.tilesM * p.tilesN;
+  const long nblk = (long)p.tilesM * p.tilesN * p.nbatch;
   if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
   MSOCR_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
@@ -391,6 +400,26 @@ extern "C" int msocr_conv2d(const msocr_conv_desc* d, const void* in, const void
   p.out_ld = d->out_ld; p.res_ld = d->res_ld;
   p.relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
   p.has_res = has_res ? 1 : 0;
+  p.nbatch = 1; p.bsA = p.bsW = p.bsO = 0;
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == MSOCR_F32 ? launch_typed<float>(p, s) : launch_typed<__bf16>(p, s);
+}
+
+// nbatch independent f32 GEMMs of one shape in ONE launch: C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]
+// (A [nbatch][M][K], B [nbatch][N][K], C [nbatch][M][N], all dense).  Used by the Winograd path (winograd.hip).
+int msocr_internal_gemm_f32_batched(const float* A, const float* B, float* C, long M, int N, int K, int nbatch, hipStream_t s) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 16 || nbatch <= 0) return MSOCR_E_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return MSOCR_E_ARG;
+  if (M > 0x7fffffffL) return MSOCR_E_ARG;
+  ConvParams p;
+  p.in = (const char*)A; p.w = (const char*)B; p.bias = nullptr; p.res = nullptr; p.out = (char*)C;
+  p.N = 1; p.H = (int)M; p.W = 1; p.Cin = K;
+  p.sN = M * (long)K; p.sH = K; p.sW = K;
+  p.KH = p.KW = 1; p.SH = p.SW = 1; p.PH = p.PW = 0;
+  p.Ho = (int)M; p.Wo = 1; p.Cout = N;
+  p.M = M; p.Ktot = K;
+  p.out_ld = N; p.res_ld = 0;
+  p.relu = 0; p.has_res = 0;
+  p.nbatch = nbatch; p.bsA = M * (long)K; p.bsW = (long)N * K; p.bsO = M * (long)N;
+  return launch_typed<float>(p, s);
 }

@@ -1,0 +1,196 @@
+// winograd.hip — 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) in f32 for gfx950 (MI355X).
+//
+// Why here: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s, 1/16 of the bf16 rate, while HBM3E
+// delivers 8 TB/s — so on this chip an f32 3x3 convolution is worth trading 2.25x fewer matrix FLOPs for two
+// streaming transform passes.  out = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A  per 2x2 output tile:
+//   1. wino_input_kernel : V[xi*4+nu][tile][c]  = (B^T d B)[xi][nu]      (HBM-bound, 16-B coalesced)
+//   2. 16 GEMMs in ONE launch of conv_igemm_kernel: Mw[p][tile][co] = sum_c V[p][tile][c] * U[p][co][c]  (MFMA)
+//   3. wino_output_kernel: out[2x2 tile][co] = act(A^T Mw A + bias (+ residual))  (HBM-bound)
+// U = G g G^T is computed once at weight-load time in f64 (msocr_winograd_weights_host).
+// The transforms only add/subtract and scale by 1/2 (exact), so the result differs from the direct f32
+// convolution by rounding order only (Lavin & Gray 2016 measure F(2x2,3x3) at or below direct-conv error).
+//
+// Replaces nn.Conv2d(3x3, stride 1, padding 1)+BatchNorm2d(+ReLU)(+add) of
+//   recognizers/_trba/model/seresnet31.py:37-45,81-89 ; detectors/_east/east.py:13-30 (conv3x3 of DecoderBlock)
+//   and the stride-1 Bottleneck conv2 of torchvision ResNet-50 (detectors/_east/east.py:56-67).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "internal.h"
+#include "msocr.h"
+
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoGeom {
+  int N, H, W;      // image extent (output extent is the same: stride 1, pad 1)
+  int TH, TW;       // 2x2-output tiles per image
+  long Mt;          // N * TH * TW
+};
+
+// ---- 1. input transform: one thread = one tile x 4 channels ------------------------------------------------
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, long sN, long sH, long sW, int C,
+                                                          WinoGeom g, float* __restrict__ V) {
+  const int cch = C >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
+  const float* base = in + (long)n * sN + c;
+  f32x4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int hi = h0 + i;
+    const bool okh = (unsigned)hi < (unsigned)g.H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wi = w0 + j;
+      const bool ok = okh && (unsigned)wi < (unsigned)g.W;
+      // branch-free: padded taps read the (always valid) first vector of the image row block and are masked to zero
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + (long)hi * sH + (long)wi * sW : base);
+      d[i][j] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+  f32x4 q[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    q[0][j] = d[0][j] - d[2][j];
+    q[1][j] = d[1][j] + d[2][j];
+    q[2][j] = d[2][j] - d[1][j];
+    q[3][j] = d[1][j] - d[3][j];
+  }
+  // (B^T d) B : columns likewise
+  const long plane = g.Mt * (long)C;
+  float* o = V + t * (long)C + c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(o + (i * 4 + 0) * plane) = q[i][0] - q[i][2];
+    *reinterpret_cast<f32x4*>(o + (i * 4 + 1) * plane) = q[i][1] + q[i][2];
+    *reinterpret_cast<f32x4*>(o + (i * 4 + 2) * plane) = q[i][2] - q[i][1];
+    *reinterpret_cast<f32x4*>(o + (i * 4 + 3) * plane) = q[i][1] - q[i][3];
+  }
+}
+
+// ---- 3. output transform: one thread = one tile x 4 output channels ---------------------------------------
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mw, int Cout, WinoGeom g,
+                                                           const float* __restrict__ bias, const float* __restrict__ res, long res_ld,
+                                                           int relu, float* __restrict__ out, long out_ld) {
+  const int cch = Cout >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const long plane = g.Mt * (long)Cout;
+  const float* mp = Mw + t * (long)Cout + c;
+  f32x4 m[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(mp + (i * 4 + j) * plane);
+  // A^T m : rows (m0+m1+m2, m1-m2-m3)
+  f32x4 s[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = (m[0][j] + m[1][j]) + m[2][j];
+    s[1][j] = (m[1][j] - m[2][j]) - m[3][j];
+  }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ho = 2 * th + i;
+    if (ho >= g.H) continue;
+    f32x4 y[2];
+    y[0] = (s[i][0] + s[i][1]) + s[i][2];
+    y[1] = (s[i][1] - s[i][2]) - s[i][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int wo = 2 * tw + j;
+      if (wo >= g.W) continue;
+      const long pix = ((long)n * g.H + ho) * g.W + wo;
+      f32x4 v = y[j] + b;
+      if (res) v += *reinterpret_cast<const f32x4*>(res + pix * res_ld + c);
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+  }
+}
+
+static bool wino_geom(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!d || d->dtype != MSOCR_F32) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1) return false;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cin <= 0 || d->Cin % 16 || d->Cout <= 0 || d->Cout % 32) return false;
+  g->N = d->N; g->H = d->H; g->W = d->W;
+  g->TH = (d->H + 1) / 2; g->TW = (d->W + 1) / 2;
+  g->Mt = (long)d->N * g->TH * g->TW;
+  return g->Mt <= 0x7fffffffL;
+}
+
+extern "C" int64_t msocr_conv3x3_winograd_workspace_bytes(const msocr_conv_desc* d) {
+  WinoGeom g;
+  if (!wino_geom(d, &g)) return -1;
+  return 16 * g.Mt * ((int64_t)d->Cin + d->Cout) * (int64_t)sizeof(float);
+}
+
+extern "C" int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                                      const void* residual, void* out, void* workspace, void* stream) {
+  WinoGeom g;
+  if (!wino_geom(d, &g) || !in || !u_weight || !out || !workspace) return MSOCR_E_ARG;
+  if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)u_weight | (uintptr_t)out | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  if (bias && ((uintptr_t)bias & 15)) return MSOCR_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* V = (float*)workspace;
+  float* Mw = V + 16 * g.Mt * (long)d->Cin;
+
+  const long th_in = g.Mt * (d->Cin / 4), th_out = g.Mt * (d->Cout / 4);
+  const long nb_in = (th_in + 255) / 256, nb_out = (th_out + 255) / 256;
+  if (nb_in > 0x7fffffffL || nb_out > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, s, (const float*)in, (long)d->in_sN, (long)d->in_sH,
+               (long)d->in_sW, d->Cin, g, V);
+  if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+  int rc = msocr_internal_gemm_f32_batched(V, u_weight, Mw, g.Mt, d->Cout, d->Cin, 16, s);
+  if (rc != MSOCR_OK) return rc;
+  MSOCR_LAUNCH(wino_output_kernel, dim3((unsigned)nb_out), dim3(256), 0, s, (const float*)Mw, d->Cout, g, bias,
+               has_res ? (const float*)residual : nullptr, (long)d->res_ld, (d->flags & MSOCR_CONV_RELU) ? 1 : 0, (float*)out,
+               (long)d->out_ld);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+// U[xi*4+nu][co][c] = sum_{kh,kw} G[xi][kh] G[nu][kw] w[co][kh][kw][c], evaluated in f64 and rounded once to f32.
+// HOST function (runs at weight-load time): w_khwc and u_out are host pointers.
+extern "C" int msocr_winograd_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {
+  if (!w_khwc || !u_out || Cout <= 0 || Cin <= 0) return MSOCR_E_ARG;
+  static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const long plane = (long)Cout * Cin;
+  for (int co = 0; co < Cout; ++co) {
+    const float* w = w_khwc + (long)co * 9 * Cin;
+    for (int c = 0; c < Cin; ++c) {
+      double gw[4][3];  // G g
+      for (int xi = 0; xi < 4; ++xi)
+        for (int kw = 0; kw < 3; ++kw)
+          gw[xi][kw] = G[xi][0] * w[(0 * 3 + kw) * Cin + c] + G[xi][1] * w[(1 * 3 + kw) * Cin + c] + G[xi][2] * w[(2 * 3 + kw) * Cin + c];
+      for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu)
+          u_out[(xi * 4 + nu) * plane + (long)co * Cin + c] =
+              (float)(gw[xi][0] * G[nu][0] + gw[xi][1] * G[nu][1] + gw[xi][2] * G[nu][2]);
+    }
+  }
+  return MSOCR_OK;
+}

@@ -33,7 +33,8 @@ def fold_bn(w, conv_bias, prefix_bn, sd):
 
 
 def to_khwc(w, dtype, device):
-    return w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device)
+    """OIHW -> [Cout][KH][KW][Cin] on the device; 3x3 f32 weights also get their Winograd twin (ops.attach_winograd)."""
+    return ops.attach_winograd(w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device))
 
 
 def pack_stem_weight(w, cin_pad, cpad=4):

@@ -5,6 +5,7 @@ Activations are NHWC tensors [N, H, W, C] (possibly channel-slice views of a wid
 concat buffer: the kernels take explicit strides / leading dimensions).
 """
 import ctypes
+import os
 
 import torch
 
@@ -43,6 +44,25 @@ def _pixel_dense_ld(t):
     return ld
 
 
+# Winograd F(2x2,3x3) for f32 3x3/1/1 convolutions with at least this many input channels (0 disables it).  Below 128
+# channels the 16 transform-domain GEMMs have K < 128 and become HBM-bound themselves.
+WINOGRAD_MIN_CIN = int(os.environ.get("MSOCR_WINOGRAD_MIN_CIN", "128"))
+
+
+def attach_winograd(w):
+    """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twin U = G g G^T ([16,Cout,Cin] f32, computed
+    on the host in f64 by msocr_winograd_weights_host).  conv2d() then takes the Winograd path for 3x3/1/1 calls."""
+    Cout, KH, KW, Cin = w.shape
+    if not (WINOGRAD_MIN_CIN and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin >= WINOGRAD_MIN_CIN and Cin % 16 == 0
+            and Cout % 32 == 0):
+        return w
+    wh = w.detach().cpu().contiguous()
+    u = torch.empty((16, Cout, Cin), dtype=torch.float32)
+    nat.check(nat.lib().msocr_winograd_weights_host(wh.data_ptr(), Cout, Cin, u.data_ptr()), "winograd_weights_host")
+    w._msocr_wino = u.to(w.device)
+    return w
+
+
 def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None, alg_k=None):
     """x [N,H,W,Cin] (any N/H/W strides, channel stride 1), w [Cout,KH,KW,Cin], bias f32 [Cout] or None.
     alg_k: algorithmic reduction length when the packed K is padded (stem), for FLOP accounting only."""
@@ -53,6 +73,8 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     sh, sw = stride
     ph, pw = pad
     Ho, Wo = out_hw if out_hw else ((H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1)
+    u = getattr(w, "_msocr_wino", None)
+    use_wino = u is not None and (sh, sw, ph, pw) == (1, 1, 1, 1) and (Ho, Wo) == (H, W)
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     assert out.shape == (N, Ho, Wo, Cout) and out.dtype == x.dtype
@@ -77,12 +99,22 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     if prof is not None:  # events are recorded on the launch stream (torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rp,
-                                out.data_ptr(), _stream())
-    nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
-    if prof is not None:
+    bp = bias.data_ptr() if bias is not None else None
+    if use_wino:
+        nbytes = nat.lib().msocr_conv3x3_winograd_workspace_bytes(ctypes.byref(d))
+        if nbytes < 0:
+            raise nat.NativeError(f"winograd: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        rc = nat.lib().msocr_conv3x3_winograd(ctypes.byref(d), x.data_ptr(), u.data_ptr(), bp, rp, out.data_ptr(), ws.data_ptr(),
+                                              _stream())
+        nat.check(rc, f"msocr_conv3x3_winograd {tuple(x.shape)} * {tuple(w.shape)}")
+    else:
+        rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
+        nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
+    if prof is not None:  # FLOPs are ALGORITHMIC (direct-convolution 2*MACs) for both paths
         e1.record()
-        prof.append((e0, e1, 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin), (N * Ho * Wo, Cout, KH * KW * Cin)))
+        prof.append((e0, e1, 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin),
+                     (N * Ho * Wo, Cout, KH * KW * Cin, "winograd" if use_wino else "direct")))
     return out
 
 

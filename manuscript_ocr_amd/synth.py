@@ -89,3 +89,167 @@ def synth_crops(seed, n, h=32, w=100):
             y1 = int(rng.integers(h // 2, h - 2))
             crops[i, y0:y1, x:x + ww] = np.clip(rng.normal(60, 25, size=(y1 - y0, ww, 3)), 0, 255).astype(np.uint8)
     return crops
+
+
+# ------------------------------------------------------------------------------------------------ synthetic weights
+# No trained checkpoint exists offline.  These generators emit seeded state_dicts in the REFERENCE key
+# layout (torchvision ResNet-50 names under `backbone.extractor.`, `decoder.block*`, `output_head.*`; `cnn.*`,
+# `enc_rnn.*`, `attn.*` for TRBA) from shape tables alone, so benchmarks and tests can build the product networks and
+# the oracle networks from the same tensors.
+def _bn(sd, g, prefix, c, gamma_scale=1.0):
+    import torch
+    sd[prefix + ".weight"] = (0.8 + 0.4 * torch.rand(c, generator=g)) * gamma_scale
+    sd[prefix + ".bias"] = 0.1 * torch.randn(c, generator=g)
+    sd[prefix + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+    sd[prefix + ".running_var"] = 0.8 + 0.4 * torch.rand(c, generator=g)
+    sd[prefix + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def _conv(sd, g, key, cout, cin, kh, kw, bias=False, gain=1.0):
+    import torch
+    sd[key + ".weight"] = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5 * gain  # He normal
+    if bias:
+        sd[key + ".bias"] = 0.1 * torch.randn(cout, generator=g)
+
+
+def east_state_dict(seed=20260128):
+    """He-normal convs, near-identity BatchNorm statistics, damped last BN of every Bottleneck (16 residual adds),
+    zero-mean score weights with bias -1.5 (~20 % of pixels above the 0.6 threshold), geometry O(10 px)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    p = "backbone.extractor."
+    _conv(sd, g, p + "conv1", 64, 3, 7, 7)
+    _bn(sd, g, p + "bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+        for b in range(blocks):
+            q = f"{p}layer{li}.{b}."
+            _conv(sd, g, q + "conv1", planes, inplanes, 1, 1)
+            _bn(sd, g, q + "bn1", planes)
+            _conv(sd, g, q + "conv2", planes, planes, 3, 3)
+            _bn(sd, g, q + "bn2", planes)
+            _conv(sd, g, q + "conv3", planes * 4, planes, 1, 1)
+            _bn(sd, g, q + "bn3", planes * 4, gamma_scale=0.35)
+            if b == 0:
+                _conv(sd, g, q + "downsample.0", planes * 4, inplanes, 1, 1)
+                _bn(sd, g, q + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    for k, (cin, mid, cout) in enumerate(((2048, 512, 512), (1536, 256, 256), (768, 128, 128), (384, 64, 32)), start=1):
+        q = f"decoder.block{k}."
+        _conv(sd, g, q + "conv1x1.0", mid, cin, 1, 1, bias=True)
+        _bn(sd, g, q + "conv1x1.1", mid)
+        _conv(sd, g, q + "conv3x3.0", cout, mid, 3, 3, bias=True)
+        _bn(sd, g, q + "conv3x3.1", cout)
+    w = torch.randn(1, 32, 1, 1, generator=g) * 0.25
+    sd["output_head.score_map.weight"] = w - w.mean()
+    sd["output_head.score_map.bias"] = torch.full((1,), -1.5)
+    sd["output_head.geo_map.weight"] = torch.randn(8, 32, 1, 1, generator=g) * 1.5
+    sd["output_head.geo_map.bias"] = 0.1 * torch.randn(8, generator=g)
+    return sd
+
+
+def trba_state_dict(num_classes=194, hidden=256, seed=20260128, rnn_scale=6.0, gen_scale=8.0, eos_period=6):
+    """He-normal CNN with near-identity BatchNorm; recurrent / attention / generator weights drawn U(-1/sqrt(H), 1/sqrt(H))
+    (PyTorch's default range) and scaled up so the decode depends on the input; and an "EOS trigger": emitting a token
+    with id % eos_period == 4 drives the decoder LSTM state along a fixed +-1 direction u that the generator's EOS row
+    reads, so sequences end at varied steps (exercises finished-beam masking and the early-break emulation)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    H, V = hidden, num_classes
+
+    def uni(*shape, k=1.0 / hidden ** 0.5, scale=1.0):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * k * scale
+
+    _conv(sd, g, "cnn.conv0.0", 64, 3, 3, 3)
+    _bn(sd, g, "cnn.conv0.1", 64)
+    _conv(sd, g, "cnn.conv0.3", 128, 64, 3, 3)
+    _bn(sd, g, "cnn.conv0.4", 128)
+    inplanes = 128
+    for li, (planes, blocks, stride) in enumerate(((256, 1, 2), (256, 2, 1), (512, 5, 2), (512, 3, 1)), start=1):
+        for b in range(blocks):
+            q = f"cnn.layer{li}.{b}."
+            _conv(sd, g, q + "conv1", planes, inplanes, 3, 3)
+            _bn(sd, g, q + "bn1", planes)
+            _conv(sd, g, q + "conv2", planes, planes, 3, 3)
+            _bn(sd, g, q + "bn2", planes)
+            sd[q + "se.fc.0.weight"] = uni(planes // 16, planes, k=1.0 / planes ** 0.5)
+            sd[q + "se.fc.2.weight"] = uni(planes, planes // 16, k=1.0 / (planes // 16) ** 0.5)
+            if b == 0 and (stride != 1 or inplanes != planes):
+                _conv(sd, g, q + "downsample.0", planes, inplanes, 1, 1)
+                _bn(sd, g, q + "downsample.1", planes)
+            inplanes = planes
+    _conv(sd, g, "cnn.conv_out.0", 512, 512, 2, 2)
+    _bn(sd, g, "cnn.conv_out.1", 512)
+    _conv(sd, g, "cnn.conv_out.3", 512, 512, 2, 2)
+    _bn(sd, g, "cnn.conv_out.4", 512)
+    for l, cin in ((0, 512), (1, H)):
+        q = f"enc_rnn.{l}."
+        for suf in ("", "_reverse"):
+            sd[q + "rnn.weight_ih_l0" + suf] = uni(4 * H, cin, scale=rnn_scale)
+            sd[q + "rnn.weight_hh_l0" + suf] = uni(4 * H, H, scale=rnn_scale)
+            sd[q + "rnn.bias_ih_l0" + suf] = uni(4 * H, scale=rnn_scale)
+            sd[q + "rnn.bias_hh_l0" + suf] = uni(4 * H, scale=rnn_scale)
+        sd[q + "linear.weight"] = uni(H, 2 * H, k=1.0 / (2 * H) ** 0.5, scale=rnn_scale)
+        sd[q + "linear.bias"] = uni(H, k=1.0 / (2 * H) ** 0.5, scale=rnn_scale)
+    a = "attn.attention_cell."
+    sd[a + "i2h.weight"] = uni(H, H, scale=rnn_scale)
+    sd[a + "h2h.weight"] = uni(H, H, scale=rnn_scale)
+    sd[a + "h2h.bias"] = uni(H, scale=rnn_scale)
+    sd[a + "score.weight"] = uni(1, H, scale=rnn_scale)
+    sd[a + "rnn.weight_ih"] = uni(4 * H, H + V, scale=rnn_scale)
+    sd[a + "rnn.weight_hh"] = uni(4 * H, H, scale=rnn_scale)
+    sd[a + "rnn.bias_ih"] = uni(4 * H, scale=rnn_scale)
+    sd[a + "rnn.bias_hh"] = uni(4 * H, scale=rnn_scale)
+    sd["attn.generator.weight"] = uni(V, H, scale=gen_scale)
+    sd["attn.generator.bias"] = uni(V)
+    if eos_period:
+        u = torch.where(torch.rand(H, generator=g) < 0.5, -1.0, 1.0)
+        w_ih = sd[a + "rnn.weight_ih"]  # [4H, H + V], gate order i,f,g,o
+        for t in range(4, V):
+            if t % eos_period == 4:
+                col = H + t
+                w_ih[0:H, col] += 6.0
+                w_ih[2 * H:3 * H, col] += 6.0 * u
+                w_ih[3 * H:4 * H, col] += 6.0
+        sd["attn.generator.weight"][2] = u * (10.0 / (0.7 * H)) + 0.1 * sd["attn.generator.weight"][2]
+    return sd
+
+
+def trba_state_dict_confident(num_classes=194, hidden=256, seed=20260128, chain=9, ctx_gain=6.0, tok_gain=10.0, gen_gain=40.0):
+    """`trba_state_dict` with a PLANTED decoder whose decisions carry large margins, as a trained checkpoint's do.
+
+    A decoder with random weights decides every character by an arg-max over near-Gaussian logits, so ~1e-5 of
+    rounding-order noise flips a few words per thousand in ANY two f32 implementations (CPU vs GPU, or CPU vs itself under
+    a 1e-5 perturbation).  Here only the FIRST character is read off the image (sign pattern of a random projection of the
+    attention context, matched against +-1 code words in the generator); every later character follows a fixed successor
+    table planted in the one-hot columns of the LSTMCell (forget gate shut, input/output gates open), ending in EOS after
+    1..`chain` steps.  CNN, BiLSTMs and the attention scorer stay random, all arithmetic stays dense, and the kernels do
+    exactly the same work; what changes is that text equality with the CPU reference is meaningful at page scale."""
+    import torch
+    sd = trba_state_dict(num_classes, hidden, seed=seed, eos_period=0)
+    g = torch.Generator().manual_seed(seed + 7)
+    H, V = hidden, num_classes
+    code = torch.where(torch.rand(V, H, generator=g) < 0.5, -1.0, 1.0)
+    nxt = list(range(V))
+    for k in range(3, V):  # tokens 3..V-1 form chains of length `chain`; the last of a chain is followed by EOS (2)
+        nxt[k] = 2 if (k - 3) % chain == chain - 1 or k == V - 1 else k + 1
+    nxt[2] = 2  # EOS repeats (rows keep running until the whole chunk is done, model.py:215,254)
+    a = "attn.attention_cell."
+    small = lambda *shape: (torch.rand(*shape, generator=g) * 2 - 1) * (0.5 / H ** 0.5)
+    w_ih, w_hh = small(4 * H, H + V), small(4 * H, H)
+    b_ih, b_hh = small(4 * H), torch.zeros(4 * H)
+    b_ih[0:H] += 8.0          # input gate open
+    b_ih[H:2 * H] -= 8.0      # forget gate shut: c = i * g
+    b_ih[3 * H:4 * H] += 8.0  # output gate open
+    w_ih[2 * H:3 * H, :H] = torch.randn(H, H, generator=g) * (ctx_gain / H ** 0.5)  # context -> g (first character)
+    for k in range(2, V):
+        w_ih[2 * H:3 * H, H + k] = tok_gain * code[nxt[k]]
+    sd[a + "rnn.weight_ih"], sd[a + "rnn.weight_hh"] = w_ih, w_hh
+    sd[a + "rnn.bias_ih"], sd[a + "rnn.bias_hh"] = b_ih, b_hh
+    sd["attn.generator.weight"] = code * (gen_gain / H) + small(V, H) * 0.1
+    gb = small(V)
+    gb[0] = gb[1] = -50.0  # PAD / SOS are never emitted
+    sd["attn.generator.bias"] = gb
+    return sd

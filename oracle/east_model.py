@@ -139,38 +139,3 @@ class EASTNet(nn.Module):  # east.py:108-139
         feats = self.backbone(x)
         score, geometry = self.output_head(self.decoder(feats))
         return {"score": score, "geometry": geometry}
-
-
-def synth_east_state_dict(seed=20260128):
-    """Seeded synthetic weights in the reference key layout.
-
-    No trained checkpoint exists offline.  He-normal conv
-    weights with BN statistics near identity keep activations O(1) through
-    the 50-layer trunk so that numeric comparisons are meaningful; the last BN
-    of every Bottleneck is damped so 16 residual adds do not blow up.
-    """
-    g = torch.Generator().manual_seed(seed)
-    net = EASTNet()
-    sd = net.state_dict()
-    for k, v in sd.items():
-        if k.endswith("num_batches_tracked"):
-            continue
-        if v.dim() == 4:  # conv weight
-            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
-            v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5)
-        elif k.endswith("running_var"):
-            v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
-        elif k.endswith("running_mean"):
-            v.copy_(0.1 * torch.randn(v.shape, generator=g))
-        elif k.endswith(".bias"):
-            v.copy_(0.1 * torch.randn(v.shape, generator=g))
-        elif k.endswith(".weight"):  # BN gamma
-            v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
-            if ".bn3." in k:
-                v.mul_(0.35)
-    # heads: keep score logits spread around 0 and geometry O(10 px)
-    w = sd["output_head.score_map.weight"]
-    w.sub_(w.mean())  # h1 is post-ReLU (positive): zero-mean weights centre the logit
-    sd["output_head.score_map.bias"].fill_(-1.5)  # ~20-25 % of pixels above the 0.6 threshold
-    sd["output_head.geo_map.weight"].mul_(6.0)
-    return sd

@@ -267,55 +267,16 @@ def texts_and_confidences(logits, ids, itos, pad_id, eos_id, blank_id=None):
         row = ids[j].tolist()
         text = decode_tokens(row, itos, pad_id, eos_id, blank_id)
         conf = logp[j, torch.arange(len(row)), row].exp().mean().item() if row else 0.0
-        res.append({"text": text, "confidence": conf})
+        res.append({"text": text, "confidence": conf, "logits0": logits[j, 0].numpy().copy()})
     return res
 
 
-def synth_trba_state_dict(num_classes=194, hidden=256, seed=20260128, gain=1.0, rnn_scale=6.0,
-                          gen_scale=8.0, eos_period=6):
-    """Seeded synthetic weights (no checkpoint exists offline).
-
-    Default PyTorch init in the reference's construction order, then: conv
-    weights re-drawn at He variance and BN statistics/affine perturbed so CNN
-    activations stay O(1); recurrent / attention / generator weights scaled up
-    so the decode is input-dependent; and an "EOS trigger": emitting a token
-    with id % eos_period == 4 drives the decoder LSTM state along a fixed +-1
-    direction u that the generator's EOS row reads, so sequences end at varied
-    steps (exercises finished-beam masking and the early-break emulation)."""
-    torch.manual_seed(seed)
-    net = TRBANet(num_classes, hidden)
-    g = torch.Generator().manual_seed(seed + 1)
-    sd = net.state_dict()
-    bn_bases = {k[: -len("running_mean")] for k in sd if k.endswith("running_mean")}
-    for k, v in sd.items():
-        if k.endswith("num_batches_tracked"):
-            continue
-        base = k[: k.rfind(".") + 1]
-        if v.dim() == 4:
-            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
-            v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5 * gain)
-        elif base in bn_bases:
-            if k.endswith("running_var"):
-                v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
-            elif k.endswith("running_mean"):
-                v.copy_(0.1 * torch.randn(v.shape, generator=g))
-            elif k.endswith(".bias"):
-                v.copy_(0.1 * torch.randn(v.shape, generator=g))
-            elif k.endswith(".weight"):
-                v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
-        elif k.startswith("enc_rnn") or k.startswith("attn.attention_cell"):
-            v.mul_(rnn_scale)
-        elif k == "attn.generator.weight":
-            v.mul_(gen_scale)
-    if eos_period:
-        H = hidden
-        u = torch.where(torch.rand(H, generator=g) < 0.5, -1.0, 1.0)
-        w_ih = sd["attn.attention_cell.rnn.weight_ih"]  # [4H, H + V], gate order i,f,g,o
-        for t in range(4, num_classes):
-            if t % eos_period == 4:
-                col = H + t
-                w_ih[0:H, col] += 6.0
-                w_ih[2 * H:3 * H, col] += 6.0 * u
-                w_ih[3 * H:4 * H, col] += 6.0
-        sd["attn.generator.weight"][2] = u * (10.0 / (0.7 * H)) + 0.1 * sd["attn.generator.weight"][2]
-    return sd
+def first_token_margin(logits0, itos, eos_id, text_a, text_b):
+    """Checker helper for page-scale text comparisons (test infrastructure, not reference behaviour): the gap, in THIS
+    CPU path's own first-step logits, between the first tokens of two decodings of one crop (EOS for an empty text).
+    Two f32 implementations may legitimately disagree on an arg-max whose margin is at rounding-noise level; with the
+    planted decoder of synth.trba_state_dict_confident every later character follows from the first one."""
+    stoi = {s: i for i, s in enumerate(itos)}
+    ta = stoi[text_a[0]] if text_a else eos_id
+    tb = stoi[text_b[0]] if text_b else eos_id
+    return abs(float(logits0[ta]) - float(logits0[tb]))

@@ -162,7 +162,7 @@ def gen_trba():
         sa, sb = ref.state_dict(), mine.state_dict()
         assert list(sa) == list(sb), [k for k in sa if k not in sb]
         assert all(torch.equal(sa[k], sb[k]) for k in sa), "seeded construction differs from reference"
-        ref.load_state_dict(otm.synth_trba_state_dict(194, 256, seed=seed), strict=True)
+        ref.load_state_dict(synth.trba_state_dict(194, 256, seed=seed), strict=True)
         ref.eval()
         crops = synth.synth_crops(seed + 2, B, h, w)
         x = torch.from_numpy(((crops.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())

@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from manuscript_ocr_amd import synth
+
 pytestmark = pytest.mark.gpu
 
 
@@ -11,7 +13,7 @@ def setup():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import east_model as oem
-    sd = oem.synth_east_state_dict(seed=20260128)
+    sd = synth.east_state_dict(seed=20260128)
     net = oem.EASTNet()
     net.load_state_dict(sd)
     net.eval()

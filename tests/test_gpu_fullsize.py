@@ -26,7 +26,7 @@ def test_east_full_resolution_maps(gpu):
     from oracle import east_model as oem
     from oracle import imgproc
     H, W = 1536, 2048
-    sd = oem.synth_east_state_dict(seed=20260128)
+    sd = synth.east_state_dict(seed=20260128)
     page = synth.synth_page(100, H, W)[0]
     ref = oem.EASTNet()
     ref.load_state_dict(sd)
@@ -49,9 +49,10 @@ def test_trba_batch256_beam_text(gpu):
     length; confidences within 1e-4."""
     from manuscript_ocr_amd import synth
     from manuscript_ocr_amd.recognizers import TRBA
+    from conftest import compare_texts
     from oracle import trba_model as otm
     seed = 20260128
-    sd = otm.synth_trba_state_dict(194, 256, seed=seed)
+    sd = synth.trba_state_dict_confident(194, 256, seed=seed)
     rec = TRBA(state_dict=sd, config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda")
     canv = synth.synth_crops(7, 256, 32, 100)
     got = rec.predict(list(canv), batch_size=256)
@@ -63,10 +64,7 @@ def test_trba_batch256_beam_text(gpu):
         lg, ids = net(x, max_len=25, mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
     itos, _ = otm.load_charset(CHARSET)
     exp = otm.texts_and_confidences(lg, ids, itos, 0, 2, None)
-    texts_g, texts_e = [r["text"] for r in got], [r["text"] for r in exp]
-    mism = sum(a != b for a, b in zip(texts_g, texts_e))
-    # the x6-amplified synthetic recurrent weights flip a near-tie about once per 1000 characters
-    assert mism <= 2, (mism, [(a, b) for a, b in zip(texts_g, texts_e) if a != b][:3])
-    same = [i for i in range(256) if texts_g[i] == texts_e[i]]
+    texts_e = [r["text"] for r in exp]
+    same = compare_texts([r["text"] for r in got], exp, itos, max_ties=2)
     np.testing.assert_allclose([got[i]["confidence"] for i in same], [exp[i]["confidence"] for i in same], atol=1e-4)
-    assert len(set(texts_e)) > 30
+    assert len(set(texts_e)) >= 20

@@ -71,6 +71,56 @@ def test_conv2d_vs_torch(ops, case, dtype, tol):
     assert err <= tol * max(scale, 1.0), (err, scale)
 
 
+WINO_CASES = [
+    # N, H, W, Cin, Cout, relu, residual     (odd H/W: partial 2x2 tiles at the bottom/right edge)
+    (2, 8, 25, 256, 256, True, False),
+    (3, 4, 13, 512, 512, True, True),
+    (1, 17, 23, 128, 64, False, False),
+    (2, 1, 7, 128, 128, True, True),
+    (1, 32, 48, 256, 128, False, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_vs_direct_and_f64(ops, case):
+    """Winograd F(2x2,3x3) path (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as
+    the direct kernel, and its error stays within 4x of the direct kernel's own error against f64 (rounding order only)."""
+    N, H, W, Cin, Cout, relu, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
+    w_direct = _w_khwc(w, torch.float32)
+    w_wino = ops.attach_winograd(_w_khwc(w, torch.float32))
+    assert getattr(w_wino, "_msocr_wino", None) is not None and not hasattr(w_direct, "_msocr_wino")
+    out_d = ops.conv2d(xd, w_direct, b.cuda(), (1, 1), (1, 1), relu, rd)
+    big = torch.full((N, H, W, Cout + 32), 7.0, device="cuda")  # written into a channel slice, like the concat buffers
+    ops.conv2d(xd, w_wino, b.cuda(), (1, 1), (1, 1), relu, rd, out=big[..., 32:])
+    torch.cuda.synchronize()
+    scale = max(ref.abs().max().item(), 1.0)
+    e_d = (out_d.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    e_w = (big[..., 32:].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert e_w <= 2e-5 * scale and e_w <= 4 * e_d + 1e-6 * scale, (e_w, e_d, scale)
+    assert torch.all(big[..., :32] == 7.0)
+
+
+def test_winograd_weight_transform_matches_definition(ops):
+    """U = G g G^T evaluated in f64 (msocr_winograd_weights_host) for every (xi, nu)."""
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(64, 128, 3, 3, generator=g)
+    wk = ops.attach_winograd(_w_khwc(w, torch.float32))
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+    exp = torch.einsum("xk,ockl,nl->xnoc", G, w.double(), G).reshape(16, 64, 128).float()
+    assert torch.equal(wk._msocr_wino.cpu(), exp)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_concat_slices(ops, dtype):
     """Input read from / output written into channel slices of wider concat buffers."""

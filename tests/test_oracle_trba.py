@@ -11,7 +11,7 @@ from oracle import trba_model as otm
 
 def _net(seed):
     net = otm.TRBANet(194, 256)
-    net.load_state_dict(otm.synth_trba_state_dict(194, 256, seed=seed), strict=True)
+    net.load_state_dict(synth.trba_state_dict(194, 256, seed=seed), strict=True)
     return net.eval()
 
 

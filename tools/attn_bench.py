@@ -5,7 +5,7 @@ import numpy as np, torch
 from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
 from oracle import trba_model as otm
 
-net = TrbaNet(otm.synth_trba_state_dict(194, 256, seed=1), 194, 256, torch.float32)
+net = TrbaNet(synth.trba_state_dict(194, 256, seed=1), 194, 256, torch.float32)
 for B in (960, 2048):
     bH = torch.randn(B, 13, 256, device="cuda")
     pH = torch.randn(B, 13, 256, device="cuda")

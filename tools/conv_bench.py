@@ -5,6 +5,8 @@ import torch
 from manuscript_ocr_amd import ops
 
 SHAPES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (960, 4, 13, 512, 512, 3, 1, 1),      # TRBA layer3/4 3x3 at the pipeline's per-group crop count
+    (960, 8, 25, 256, 256, 3, 1, 1),
     (2048, 4, 13, 512, 512, 3, 1, 1),     # TRBA layer3/4 3x3 (45 launches/step)
     (2048, 8, 25, 256, 256, 3, 1, 1),     # TRBA layer2
     (2048, 16, 50, 64, 128, 3, 1, 1),     # TRBA conv0b
@@ -19,6 +21,8 @@ def main():
     for (N, H, W, Cin, Cout, k, s, p) in SHAPES:
         x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
         w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
+        if os.environ.get("WINO", "1") == "1":
+            ops.attach_winograd(w)
         b = torch.randn(Cout, device="cuda")
         out = ops.conv2d(x, w, b, (s, s), (p, p), True)
         torch.cuda.synchronize()
@@ -32,7 +36,8 @@ def main():
         ms = e0.elapsed_time(e1) / iters
         Ho, Wo = out.shape[1], out.shape[2]
         fl = 2.0 * N * Ho * Wo * Cout * k * k * Cin
-        print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{k}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s")
+        print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} k{k} {'wino' if hasattr(w, '_msocr_wino') else 'direct'}: {ms:.3f} ms  "
+              f"{fl / ms / 1e9:.1f} TF/s (algorithmic)")
 
 if __name__ == "__main__":
     main()
