@@ -103,16 +103,17 @@ def main():
         return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
 
     def run_steps(k):
-        """k steps; with the pipeline workload the detector work of step i+1 is enqueued (on the other stream set)
-        before step i is collected, so the device never drains between steps.  All work of the k steps is inside."""
+        """k steps, software-pipelined across steps: the detector work of step i+1 is enqueued and its host stage
+        (box filters, reading order, crop descriptors -> recogniser enqueue) runs BEFORE step i is collected, so the
+        device always holds queued recogniser work while the host annotates step i.  All work of the k steps is inside."""
         if pipe is None or a.serialize_streams or a.no_overlap_steps:
             out_ = None
             for _ in range(k):
                 out_ = step()
             return out_
-        h, out_ = submit(), None
+        h, out_ = pipe.advance_batch(submit()), None
         for i in range(k):
-            h_next = submit() if i + 1 < k else None
+            h_next = pipe.advance_batch(submit()) if i + 1 < k else None
             out_ = pipe.collect_batch(h)
             h = h_next
         return out_

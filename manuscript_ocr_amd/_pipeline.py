@@ -9,6 +9,8 @@ here it is the per-image `predict`.  `predict_batch` is the MI355X fast path: wh
 recogniser are this package's EAST/TRBA it runs the detector once for all pages and the
 recogniser once for all crops of all pages (results identical to per-page predict).
 """
+import contextlib
+import gc
 import time
 from typing import List, Optional, Union
 
@@ -17,6 +19,20 @@ from PIL import Image
 
 from .detectors import EAST, read_image, sort_boxes_reading_order_with_resolutions, visualize_page
 from .recognizers import TRBA
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    """The batch path creates ~10^5 small container objects per step (Words, polygons, result rows); with the cyclic GC
+    enabled, generation-2 passes over them land in the middle of the enqueue path (measured ~10 ms per group).  Nothing
+    here forms reference cycles, so reference counting alone frees everything; the collector's state is restored on exit."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _word_aabb(word):
@@ -191,68 +207,88 @@ class Pipeline:
         return {"arrays": arrays, "pages_dev": pages_dev, "bounds": bounds, "streams": streams, "main": main,
                 "det_handles": det_handles, "recognize_text": recognize_text, "profile": profile}
 
-    def collect_batch(self, h):
-        """Stages 2-3 of `predict_batch` for a handle from `submit_batch` -> list of Pages."""
+    def advance_batch(self, h):
+        """Stage 2 of `predict_batch` for a handle from `submit_batch`: per group — wait for its boxes, run the host
+        tail + reading order, then enqueue device crops + the recogniser (asynchronous).  Idempotent.  Calling it for
+        batch i+1 BEFORE `collect_batch` of batch i keeps recogniser work queued on the device while the host
+        annotates batch i (bench.py does)."""
+        if h.get("groups") is not None:
+            return h
         import torch
 
         from . import ops
         det, rec = self.detector, self.recognizer
-        arrays, pages_dev, bounds, streams, main = h["arrays"], h["pages_dev"], h["bounds"], h["streams"], h["main"]
+        arrays, pages_dev, bounds, streams = h["arrays"], h["pages_dev"], h["bounds"], h["streams"]
         recognize_text, profile = h["recognize_text"], h["profile"]
         tm = {"detect_wait+tail": 0.0, "order": 0.0, "crop+enqueue": 0.0, "recognize_wait": 0.0, "assign": 0.0}
         N = len(arrays)
         H, W = arrays[0].shape[:2]
-        # stage 2: per group — wait for its boxes, host tail + reading order, enqueue crops + recogniser (async)
         pages, groups = [None] * N, []
-        for (lo, hi), st, dh in zip(bounds, streams, h["det_handles"]):
-            with torch.cuda.stream(st):
-                t0 = time.perf_counter()
-                res = det.detect_finish(dh, arrays[lo:hi], profile=profile)
-                tm["detect_wait+tail"] += time.perf_counter() - t0
-                grp = {"words": [], "spans": [], "handle": None}
-                if recognize_text:
-                    t0 = time.perf_counter()
-                    boxes, page_ids = [], []
-                    for pi, r in enumerate(res):
-                        page = self._page_of(r)
-                        pages[lo + pi] = page
-                        words, bxs = self._order_boxes(page)
-                        grp["spans"].append([len(grp["words"]), len(words)])
-                        grp["words"] += words
-                        boxes += bxs
-                        page_ids += [lo + pi] * len(bxs)
-                    tm["order"] += time.perf_counter() - t0
-                    t0 = time.perf_counter()
-                    if boxes:
-                        desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
-                        if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
-                            grp["words"] = [w for w, k in zip(grp["words"], keep) if k]
-                            kept_pages = np.asarray(page_ids)[keep]
-                            grp["spans"], n0 = [], 0
-                            for pi in range(lo, hi):
-                                c = int((kept_pages == pi).sum())
-                                grp["spans"].append([n0, c])
-                                n0 += c
-                        if len(desc):
-                            canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-                            grp["handle"] = rec.recognize_start(canv)
-                    tm["crop+enqueue"] += time.perf_counter() - t0
-                else:
-                    for pi, r in enumerate(res):
-                        pages[lo + pi] = self._page_of(r)
-                groups.append(grp)
-        # stage 3: per group — finish the recogniser (sync) and annotate the words
-        for grp, st in zip(groups, streams):
-            if grp["handle"] is not None:
+        with _gc_paused():
+            for (lo, hi), st, dh in zip(bounds, streams, h["det_handles"]):
                 with torch.cuda.stream(st):
                     t0 = time.perf_counter()
-                    out = rec.recognize_finish(grp["handle"], spans=[tuple(s) for s in grp["spans"] if s[1] > 0])
-                    tm["recognize_wait"] += time.perf_counter() - t0
-                t0 = time.perf_counter()
-                self._assign(grp["words"], rec._results(*out))
-                tm["assign"] += time.perf_counter() - t0
-            if st is not main:
-                main.wait_stream(st)
+                    res = det.detect_finish(dh, arrays[lo:hi], profile=profile)
+                    tm["detect_wait+tail"] += time.perf_counter() - t0
+                    grp = {"words": [], "spans": [], "handle": None}
+                    if recognize_text:
+                        t0 = time.perf_counter()
+                        boxes, page_ids = [], []
+                        for pi, r in enumerate(res):
+                            page = self._page_of(r)
+                            pages[lo + pi] = page
+                            words, bxs = self._order_boxes(page)
+                            grp["spans"].append([len(grp["words"]), len(words)])
+                            grp["words"] += words
+                            boxes += bxs
+                            page_ids += [lo + pi] * len(bxs)
+                        tm["order"] += time.perf_counter() - t0
+                        t0 = time.perf_counter()
+                        if boxes:
+                            desc, keep = ops.crop_descriptors(boxes, page_ids, (H, W), rec.img_h, rec.img_w)
+                            if not keep.all():  # empty clamped crops are skipped by the reference (_pipeline.py:135)
+                                grp["words"] = [w for w, k in zip(grp["words"], keep) if k]
+                                kept_pages = np.asarray(page_ids)[keep]
+                                grp["spans"], n0 = [], 0
+                                for pi in range(lo, hi):
+                                    c = int((kept_pages == pi).sum())
+                                    grp["spans"].append([n0, c])
+                                    n0 += c
+                            if len(desc):
+                                canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
+                                grp["handle"] = rec.recognize_start(canv)
+                        tm["crop+enqueue"] += time.perf_counter() - t0
+                    else:
+                        for pi, r in enumerate(res):
+                            pages[lo + pi] = self._page_of(r)
+                    groups.append(grp)
+        h["pages"], h["groups"], h["tm"] = pages, groups, tm
+        return h
+
+    def collect_batch(self, h):
+        """Stages 2-3 of `predict_batch` for a handle from `submit_batch` -> list of Pages (stage 2 = `advance_batch`,
+        skipped when already done; stage 3 = per group: finish the recogniser (sync) and annotate the words)."""
+        import torch
+
+        self.advance_batch(h)
+        rec = self.recognizer
+        streams, main, profile = h["streams"], h["main"], h["profile"]
+        pages, groups, tm = h["pages"], h["groups"], h["tm"]
+        with _gc_paused():
+            for grp, st in zip(groups, streams):
+                if grp["handle"] is not None:
+                    with torch.cuda.stream(st):
+                        t0 = time.perf_counter()
+                        ids, trun, conf = rec.recognize_finish(grp["handle"], spans=[tuple(s) for s in grp["spans"] if s[1] > 0])
+                        tm["recognize_wait"] += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    texts = rec.texts(ids, trun)
+                    for word, text, c in zip(grp["words"], texts, conf.tolist()):
+                        word.text = text
+                        word.recognition_confidence = c
+                    tm["assign"] += time.perf_counter() - t0
+                if st is not main:
+                    main.wait_stream(st)
         self.last_profile = tm
         if profile:
             print("Pipeline.predict_batch host stages (s):", {k: round(v, 4) for k, v in tm.items()})

@@ -347,7 +347,9 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
   constexpr int ES = sizeof(T);
   // row bytes: 128 B when Cin allows (f32: BK 32, bf16: BK 64), else 64 B
   const bool wide = (p.Cin * ES) % 128 == 0;
-  static const int variant = getenv("MSOCR_CONV_VARIANT") ? atoi(getenv("MSOCR_CONV_VARIANT")) : 0;
+  // variant 1 (default for f32): ONE LDS stage, 3 workgroups per CU — a third resident workgroup covers the other two's
+  // prologue/epilogue, worth 3-5 % on the short-K (Winograd, 1x1) launches; variant 0: register-staged double buffer, 2/CU.
+  static const int variant = getenv("MSOCR_CONV_VARIANT") ? atoi(getenv("MSOCR_CONV_VARIANT")) : (sizeof(T) == 4 ? 1 : 0);
   if (p.Cout % 128 == 0) {
     if (wide && variant == 1) return launch_cfg<T, 128, 128, 128, 64, 64, 1>(p, s);
     if (variant == 2 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1>(p, s);

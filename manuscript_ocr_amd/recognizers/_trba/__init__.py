@@ -204,6 +204,20 @@ class TRBA:
         """canvases [N,img_h,img_w,3] u8 on device -> (ids [N,steps] i32, t_run [N] i32, conf [N] f32[, logits]) on host."""
         return self.recognize_finish(self.recognize_start(canvases_dev, mode, beam_size, temperature, alpha), batch_size, spans, return_logits)
 
+    def texts(self, ids, trun) -> List[str]:
+        """decode_tokens (transforms.py:196-206) over the first t_run ids of every row, vectorised: the text ends at the
+        first EOS; PAD (and BLANK) ids are skipped."""
+        ids = np.asarray(ids)
+        T = ids.shape[1] if ids.ndim == 2 else 0
+        if not len(ids) or T == 0:
+            return ["" for _ in range(len(ids))]
+        pos = np.arange(T)[None, :]
+        stop = (ids == self.eos_id) | (pos >= np.asarray(trun)[:, None])
+        end = np.where(stop.any(axis=1), stop.argmax(axis=1), T)
+        itos, skip = self.itos, {self.pad_id, self.blank_id}
+        rows = ids.tolist()
+        return ["".join([itos[t] for t in row[:e] if t not in skip]) for row, e in zip(rows, end.tolist())]
+
     def _results(self, ids, trun, conf) -> List[Dict[str, Any]]:
         """__init__.py:415-432: decode_tokens over the t_run generated ids; confidence computed on the device."""
         return [{"text": decode_tokens(ids[j, : int(trun[j])], self.itos, self.pad_id, self.eos_id, self.blank_id),

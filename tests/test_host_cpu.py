@@ -195,3 +195,24 @@ def test_pipeline_order_boxes_equals_oracle_order_and_crop():
         for d, c in zip(desc, crops):
             assert (d[4] - d[2], d[3] - d[1]) == c.shape[:2]
             assert np.array_equal(img[d[2]:d[4], d[1]:d[3]], c)
+
+
+def test_vectorised_texts_equal_decode_tokens():
+    """TRBA.texts (vectorised) == decode_tokens over ids[:t_run] row by row (transforms.py:196-206 semantics)."""
+    import types
+
+    from manuscript_ocr_amd.recognizers import TRBA
+    from manuscript_ocr_amd.recognizers._trba.transforms import decode_tokens
+    rng = np.random.default_rng(5)
+    itos = [f"<{i}>" if i < 4 else chr(0x410 + i) for i in range(60)]
+    for blank in (None, 3):
+        stub = types.SimpleNamespace(itos=itos, pad_id=0, eos_id=2, blank_id=blank)
+        ids = rng.integers(0, 60, size=(200, 12)).astype(np.int32)
+        ids[rng.random((200, 12)) < 0.15] = 2
+        ids[rng.random((200, 12)) < 0.10] = 0
+        trun = rng.integers(0, 13, size=200).astype(np.int32)
+        for j in range(200):
+            ids[j, trun[j]:] = -1  # what msocr_attn_beam_finalize leaves beyond t_run
+        exp = [decode_tokens(ids[j, : int(trun[j])], itos, 0, 2, blank) for j in range(200)]
+        assert TRBA.texts(stub, ids, trun) == exp
+    assert TRBA.texts(stub, np.zeros((0, 5), np.int32), np.zeros((0,), np.int32)) == []
