@@ -145,6 +145,12 @@ typedef struct msocr_attn_weights {
  *         tokens and the arg-max beam into `workspace`, and fin_step_out[b] = number of steps after which every
  *         beam of row b is finished (or steps).  lp_dev[steps] = f32 length-penalty factors
  *         ((5+t+1)^alpha / 6^alpha, computed by the host exactly as model.py:160) or NULL when alpha <= 0.
+ *         Optional early exit (all three pointers non-NULL): chunk_id_dev[B] = index of the reference chunk (the slice of
+ *         batch_size crops one model call sees) of every row, chunk_size_dev[nchunks] = rows per chunk, all of them inside
+ *         this call; chunk_state_dev[2*nchunks] int32 zeroed by the caller.  A workgroup then leaves the step loop once every
+ *         chunk its rows belong to is completely finished (model.py:215), so steps >= the chunk's run length are skipped.
+ *         The default kernel runs the three matrix products of a step on the f32 matrix cores, 4 rows x 8 beams per
+ *         workgroup (csrc/attn_beam_mfma.hip); MSOCR_BEAM_MFMA=0 selects the VALU kernel (one row per workgroup).
  * The reference stops the loop for the whole batch chunk (model.py:215,254); the host derives each row's run length
  * t_run from ids/fin_step and msocr_attn_beam_finalize walks the back-pointers from (t_run-1, best beam at t_run-1):
  * logits_out [B][steps][V] (rows t < t_run valid), ids_out [B][steps] (-1 beyond t_run). */
@@ -154,7 +160,8 @@ int msocr_attn_greedy(const float* batch_H, const float* proj_H, const msocr_att
 int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, int V);
 int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H,
                     int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
-                    int blank_id, int32_t* fin_step_out, void* workspace, void* stream);
+                    int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
+                    const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
 int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                              float* logits_out, int32_t* ids_out, void* stream);
 

@@ -256,7 +256,7 @@ class Pipeline:
                                     n0 += c
                             if len(desc):
                                 canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-                                grp["handle"] = rec.recognize_start(canv)
+                                grp["handle"] = rec.recognize_start(canv, spans=[tuple(s) for s in grp["spans"] if s[1] > 0])
                         tm["crop+enqueue"] += time.perf_counter() - t0
                     else:
                         for pi, r in enumerate(res):

@@ -1,0 +1,472 @@
+// attn_beam_mfma.hip — beam-search attention decode of the TRBA recogniser with the step's three matrix products on
+// the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 products and sums).
+//
+// One 512-thread workgroup owns NB = 4 crops x 8 beam slots = 32 state rows for the whole step loop (rows of different
+// crops are independent: no inter-workgroup hand-off).  32 rows are exactly one MFMA row block, so every weight element a
+// workgroup pulls from L2 now feeds 32 rows instead of the 8 of the VALU kernel (trba_kernels.hip): the L2 -> CU weight
+// stream that bounded that kernel (2.5 MB per step per workgroup) is shared by 4x more work, and the gate arithmetic
+// moves off the VALU.  Per step:
+//   (a) ph    = h2h(h)                     [32x256] x [256x256]        MFMA  (wave w: columns 32w..32w+31)
+//   (b) e     = score . tanh(proj_H + ph)  32 x T dot products          VALU  (one wave per (row, t) pair)
+//   (c) alpha = softmax_t(e)                                            VALU
+//   (d) ctx   = alpha . batch_H                                         VALU
+//   (e) gates = [ctx | h] x [W_ih_ctx ; W_hh]^T + W_ih_tok[token] + b   [32x512] x [512x1024]  MFMA
+//       (wave w owns hidden units 32w..32w+31; one 16-byte load per lane = the unit's 4 gates = B operands of 4 MFMAs,
+//        so the LSTM cell update is lane-local in the accumulator layout)
+//   (f) logits = generator(h')             [32x256] x [256xV]          MFMA
+//   (g-j) temperature, log-softmax, top-8 of 8*V candidates per crop, back-pointers, beam state permutation   VALU/LDS
+// Same outputs, workspace layout and tie rules as attn_beam_kernel (larger value first, then smaller flat index).
+//
+// Replaces recognizers/_trba/model/model.py:34-46 (AttentionCell.forward) + :92-225 (Attention._beam_decode).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "internal.h"
+#include "msocr.h"
+
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int H = 256;        // hidden size (ATT_H)
+constexpr int KB8 = 8;        // beam slots per crop (ATT_KMAX)
+constexpr int NB = 4;         // crops per workgroup
+constexpr int R = NB * KB8;   // 32 state rows = one MFMA row block
+constexpr int XS = 2 * H + 4; // row stride of X = [ctx | h] in floats: 516 -> ds_read_b128 of 32 rows is conflict-free
+constexpr int NT = 512;       // threads per workgroup
+
+// Hardware-rate transcendentals (v_exp_f32 / v_rcp_f32, ~1-2 ulp each): the decode step evaluates 32 x T x 256 tanh and
+// 5 x 32 x 256 gate activations on the VALU between the matrix phases; libm-grade expf/tanhf made that the longest phase.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fexp(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// row of accumulator register e in the 32x32 MFMA output layout (lane half = lane >> 5)
+__device__ __forceinline__ int acc_row(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Weight streams use buffer loads: ONE per-lane byte offset in a VGPR (loop-invariant) + a scalar byte offset per load, so
+// the 12-16 loads in flight cost no address VGPRs (a global_load needs a 64-bit VGPR address each); out-of-range lanes
+// (generator columns >= V) read 0 by the buffer range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int nfloats) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nfloats * 4, 0x00020000);
+}
+
+// D[32 rows][32 columns of this wave] += X[:, k0 : k0+256] * W[k][col], W row-major with `ldw` floats per k, one dword per lane.
+__device__ __forceinline__ void mfma_cols32(const float* __restrict__ sX, int k0, const float* __restrict__ W, int ldw, int col,
+                                            bool col_ok, int r32, int half, f32x16& acc) {
+  constexpr int PFQ = 4;  // k-groups (of 8) of weight loads kept in flight
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(W, H * ldw);
+  const int voff = col_ok ? (4 * half * ldw + col) * 4 : 0x7ffffff0;
+  const int kstep = ldw * 4;  // bytes between consecutive k
+  float wb[PFQ][4];
+#pragma unroll
+  for (int pq = 0; pq < PFQ; ++pq)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wb[pq][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (8 * pq + e) * kstep, 0));
+#pragma unroll 1
+  for (int q0 = 0; q0 < H / 8; q0 += PFQ) {
+#pragma unroll
+    for (int pq = 0; pq < PFQ; ++pq) {
+      const int q = q0 + pq;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sX[r32 * XS + k0 + 8 * q + 4 * half]);
+      float cur[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[e] = wb[pq][e];
+      const int qn = q + PFQ;
+      if (qn < H / 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wb[pq][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (8 * qn + e) * kstep, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], cur[e], acc, 0, 0, 0);
+    }
+  }
+}
+
+// gates of hidden units 32w..32w+31: acc[g] += X[:, k0 : k0+256] * Wt[k][j][g]   (Wt gate-interleaved: [k][j][4])
+__device__ __forceinline__ void mfma_gates(const float* __restrict__ sX, int k0, const float* __restrict__ Wt, int j, int r32, int half,
+                                           f32x16 (&acc)[4]) {
+  constexpr int PFQ = 4;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(Wt, H * H * 4);
+  const int voff = (4 * half * H + j) * 16;
+  constexpr int kstep = H * 16;
+  f32x4 wb[PFQ][4];
+#pragma unroll
+  for (int pq = 0; pq < PFQ; ++pq)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      wb[pq][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (8 * pq + e) * kstep, 0));
+#pragma unroll 1
+  for (int q0 = 0; q0 < H / 8; q0 += PFQ) {
+#pragma unroll
+    for (int pq = 0; pq < PFQ; ++pq) {
+      const int q = q0 + pq;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sX[r32 * XS + k0 + 8 * q + 4 * half]);
+      f32x4 cur[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[e] = wb[pq][e];
+      const int qn = q + PFQ;
+      if (qn < H / 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          wb[pq][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (8 * qn + e) * kstep, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], cur[e][g], acc[g], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sX = lds;                 // [R][XS]   ctx (0..255) | h (256..511)
+  float* sbuf = sX + R * XS;       // [R][H]    ph, then logits, then scratch of the state permutation
+  float* salpha = sbuf + R * H;    // [R][64]
+  __shared__ float s_score[R], s_lse[R], s_top[R];
+  __shared__ int s_tok[R], s_done[R], s_src[R], s_nxt[R], s_fin[NB], s_exit;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int T = a.T, V = a.V, KB = a.K;
+  const int b0 = blockIdx.x * NB;
+  const int ju = 32 * wv + r32;    // hidden unit / output column owned in the MFMA phases
+
+  for (int i = tid; i < R * H; i += NT) sX[(i >> 8) * XS + H + (i & 255)] = 0.f;  // h = 0
+  f32x16 c;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  if (tid < R) {
+    s_score[tid] = (tid % KB8) == 0 ? 0.f : -INFINITY;
+    s_tok[tid] = a.sos_id;
+    s_done[tid] = 0;
+  }
+  if (tid < NB) s_fin[tid] = a.steps;
+  __syncthreads();
+  const float temp = fmaxf(a.temperature, 1e-6f);
+
+  for (int s = 0; s < a.steps; ++s) {
+    // ---- (a) ph[r][j] = h2h_b[j] + sum_k h[r][k] * h2h_wt[k][j]
+    if (!(a.dbg & 1)) {
+      f32x16 acc;
+      const float bj = a.w.h2h_b[ju];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = bj;
+      mfma_cols32(sX, H, a.w.h2h_wt, H, ju, true, r32, half, acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = acc[e];
+    }
+    __syncthreads();
+    // ---- (b) e[r][t] = sum_j score_w[j] * tanh(proj_H[crop][t][j] + ph[r][j]) : one wave per (crop, t) group — the
+    //      proj_H row is read once for the crop's 8 beams; the rows of up to GB groups are in flight together
+    if (!(a.dbg & 2)) {
+      constexpr int GB = 4;
+      float sw[H / 64];
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) sw[q] = a.w.score_w[lane + 64 * q];
+      const int ngroups = NB * T;
+      for (int g0 = wv; g0 < ngroups; g0 += GB * (NT / 64)) {
+        float pr[GB][H / 64];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int g = g0 + u * (NT / 64);
+          if (g < ngroups) {
+            const int nb = g / T, t = g - nb * T;
+            const float* pP = a.proj_H + ((long)min(b0 + nb, a.B - 1) * T + t) * H;
+#pragma unroll
+            for (int q = 0; q < H / 64; ++q) pr[u][q] = pP[lane + 64 * q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int g = g0 + u * (NT / 64);
+          if (g < ngroups) {
+            const int nb = g / T, t = g - nb * T;
+            float sacc[KB8];
+#pragma unroll
+            for (int rb = 0; rb < KB8; ++rb) {
+              const int r = nb * KB8 + rb;
+              sacc[rb] = 0.f;
+#pragma unroll
+              for (int q = 0; q < H / 64; ++q) sacc[rb] = fmaf(sw[q], ftanh(pr[u][q] + sbuf[r * H + lane + 64 * q]), sacc[rb]);
+            }
+            // 8 independent butterfly reductions, interleaved (the cross-lane latency of one hides behind the others)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+              for (int rb = 0; rb < KB8; ++rb) sacc[rb] += __shfl_xor(sacc[rb], o);
+            if (lane < KB8) {
+              float v = sacc[0];
+#pragma unroll
+              for (int rb = 1; rb < KB8; ++rb) v = (lane == rb) ? sacc[rb] : v;
+              salpha[(nb * KB8 + lane) * 64 + t] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (c) softmax over t
+    if (tid < R) {
+      float m = -INFINITY;
+      for (int t = 0; t < T; ++t) m = fmaxf(m, salpha[tid * 64 + t]);
+      float sum = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const float ev = expf(salpha[tid * 64 + t] - m);
+        salpha[tid * 64 + t] = ev;
+        sum += ev;
+      }
+      for (int t = 0; t < T; ++t) salpha[tid * 64 + t] = salpha[tid * 64 + t] / sum;
+    }
+    __syncthreads();
+    // ---- (d) ctx[r][j] = sum_t alpha[r][t] * batch_H[crop(r)][t][j] : thread = (j, half of the crops)
+    if (!(a.dbg & 4)) {
+      const int j = tid & 255, ch = tid >> 8;
+#pragma unroll
+      for (int n2 = 0; n2 < NB / 2; ++n2) {
+        const int nb = ch * (NB / 2) + n2;
+        const int b = min(b0 + nb, a.B - 1);
+        const float* pH = a.batch_H + (long)b * T * H + j;
+        float accd[KB8];
+#pragma unroll
+        for (int q = 0; q < KB8; ++q) accd[q] = 0.f;
+        for (int t0 = 0; t0 < T; t0 += 16) {  // 16 independent loads in flight, then the FMAs
+          float hv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) hv[u] = (t0 + u < T) ? pH[(long)(t0 + u) * H] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (t0 + u < T) {
+#pragma unroll
+              for (int q = 0; q < KB8; ++q) accd[q] = fmaf(salpha[(nb * KB8 + q) * 64 + t0 + u], hv[u], accd[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KB8; ++q) sX[(nb * KB8 + q) * XS + j] = accd[q];
+      }
+    }
+    __syncthreads();
+    // ---- (e) gates + LSTM cell for units ju, rows acc_row(e, half)
+    {
+      f32x16 acc[4];
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&a.w.b_gates[ju * 4]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tk = s_tok[acc_row(e, half)];
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&a.w.wih_tok[((long)tk * H + ju) * 4]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g][e] = b4[g] + t4[g];
+      }
+      if (!(a.dbg & 8)) {
+        mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+        mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
+      }
+      __syncthreads();  // every wave has read the old h
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float ig = sigmoidf_(acc[0][e]), fg = sigmoidf_(acc[1][e]), gg = ftanh(acc[2][e]), og = sigmoidf_(acc[3][e]);
+        c[e] = fg * c[e] + ig * gg;
+        sX[acc_row(e, half) * XS + H + ju] = og * ftanh(c[e]);
+      }
+    }
+    __syncthreads();
+    // ---- (f) logits[r][v] = gen_b[v] + sum_k h'[r][k] * gen_wt[k][v]; temperature; trace store
+    {
+      const bool vok = ju < V;
+      f32x16 acc;
+      const float bv = vok ? a.w.gen_b[ju] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = bv;
+      if (32 * wv < V && !(a.dbg & 16)) mfma_cols32(sX, H, a.w.gen_wt, V, ju, vok, r32, half, acc);
+      if (vok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = acc_row(e, half);
+          float v = (ju == a.blank_id) ? -1e4f : acc[e];
+          if (a.temperature != 1.0f) v = v / temp;  // true f32 division (model.py:135-137)
+          sbuf[r * H + ju] = v;
+          const int b = b0 + r / KB8, rb = r % KB8;
+          if (rb < KB && b < a.B) a.logits_out[(((long)b * a.steps + s) * KB + rb) * V + ju] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (g) log-sum-exp per row: wave w handles rows 4w..4w+3
+    for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
+      float m = -INFINITY;
+      for (int v = lane; v < V; v += 64) m = fmaxf(m, sbuf[r * H + v]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int v = lane; v < V; v += 64) sum += expf(sbuf[r * H + v] - m);
+      sum = wave_sum(sum);
+      if (lane == 0) s_lse[r] = m + logf(sum);
+    }
+    __syncthreads();
+    // ---- (h) top-K of the K*V candidates of every crop: ONE wave per crop (lane owns v = lane + 64 i), the K rounds of
+    //      arg-max + winner removal need no workgroup barrier.  Order: larger value, then smaller flat index beam*V + v.
+    const float lp = a.lp ? a.lp[s] : 1.0f;
+    if (!(a.dbg & 32) && wv < NB) {
+      const int nb = wv;
+      constexpr int VI = 4;  // V <= 256
+      float cv[VI][KB8];
+#pragma unroll
+      for (int i = 0; i < VI; ++i) {
+        const int v = lane + 64 * i;
+#pragma unroll
+        for (int rb = 0; rb < KB8; ++rb) {
+          cv[i][rb] = -INFINITY;
+          const int r = nb * KB8 + rb;
+          if (v < V && rb < KB) {
+            float logp = sbuf[r * H + v] - s_lse[r];
+            if (s_done[r]) logp = (v == a.eos_id) ? 0.f : -INFINITY;
+            float tot = s_score[r] + logp;
+            if (a.lp) tot = tot / lp;
+            cv[i][rb] = tot;
+          }
+        }
+      }
+      for (int kk = 0; kk < KB; ++kk) {
+        float bvv = -INFINITY;
+        int bii = 0x7fffffff;
+#pragma unroll
+        for (int rb = 0; rb < KB8; ++rb)
+#pragma unroll
+          for (int i = 0; i < VI; ++i) {
+            const int v = lane + 64 * i, fi = rb * V + v;
+            const float x = cv[i][rb];
+            if (v < V && rb < KB && (x > bvv || (x == bvv && fi < bii))) { bvv = x; bii = fi; }
+          }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bvv, o);
+          const int oi = __shfl_xor(bii, o);
+          if (ov > bvv || (ov == bvv && oi < bii)) { bvv = ov; bii = oi; }
+        }
+        int wi_ = bii;
+        if (wi_ == 0x7fffffff) wi_ = 0;  // every candidate NaN: degenerate input
+        const int wr = wi_ / V, wc = wi_ - wr * V;
+        if (lane == 0) {
+          s_top[nb * KB8 + kk] = bvv;
+          s_src[nb * KB8 + kk] = wr;
+          s_nxt[nb * KB8 + kk] = wc;
+        }
+#pragma unroll
+        for (int rb = 0; rb < KB8; ++rb)
+#pragma unroll
+          for (int i = 0; i < VI; ++i)
+            if (rb == wr && lane + 64 * i == wc) cv[i][rb] = __int_as_float(0x7fc00000);  // the winner never wins again
+      }
+    }
+    __syncthreads();
+    // ---- (i) bookkeeping per state row
+    int nd = 1;
+    if (tid < R) {
+      const int nb = tid / KB8, rb = tid % KB8;
+      if (rb < KB) nd = s_done[nb * KB8 + s_src[tid]] | (s_nxt[tid] == a.eos_id);
+    }
+    __syncthreads();
+    if (tid < R) {
+      const int nb = tid / KB8, rb = tid % KB8, b = b0 + nb;
+      if (rb < KB) {
+        if (b < a.B) {
+          const long o = ((long)b * a.steps + s) * KB + rb;
+          a.back[o] = s_src[tid];
+          a.tokv[o] = s_nxt[tid];
+        }
+        s_score[tid] = a.lp ? s_top[tid] * lp : s_top[tid];  // f32 round trip of the reference (model.py:188-192)
+        s_tok[tid] = s_nxt[tid];
+      }
+      s_done[tid] = nd;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      int best = 0, all = 1;
+      float bs = s_score[tid * KB8];
+      for (int r = 0; r < KB; ++r) {
+        if (r && s_score[tid * KB8 + r] > bs) { bs = s_score[tid * KB8 + r]; best = r; }
+        all &= s_done[tid * KB8 + r];
+      }
+      if (b0 + tid < a.B) a.best_at[(long)(b0 + tid) * a.steps + s] = best;
+      if (all && s_fin[tid] == a.steps) {
+        s_fin[tid] = s + 1;
+        if (a.chunk_state && b0 + tid < a.B) {  // publish: max finish step first, then the count that readers test
+          const int ch = a.chunk_id[b0 + tid];
+          atomicMax(&a.chunk_state[2 * ch + 1], s + 1);
+          __threadfence();
+          atomicAdd(&a.chunk_state[2 * ch], 1);
+        }
+      }
+    }
+    // ---- (j) permute beam state by src within every crop: c through sbuf (logits are consumed), h through registers
+    if (!(a.dbg & 64)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = c[e];
+      const int j = tid & 255, ch = tid >> 8;
+      float hn[R / 2];
+#pragma unroll
+      for (int q = 0; q < R / 2; ++q) {
+        const int r = ch * (R / 2) + q, nb = r / KB8, rb = r % KB8;
+        const int src = rb < KB ? s_src[r] : rb;
+        hn[q] = sX[(nb * KB8 + src) * XS + H + j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = acc_row(e, half), nb = r / KB8, rb = r % KB8;
+        const int src = rb < KB ? s_src[r] : rb;
+        c[e] = sbuf[(nb * KB8 + src) * H + ju];
+      }
+#pragma unroll
+      for (int q = 0; q < R / 2; ++q) sX[(ch * (R / 2) + q) * XS + H + j] = hn[q];
+    }
+    __syncthreads();
+    // ---- early exit (model.py:215 breaks the loop once every beam of every row of the chunk is finished): leave after
+    //      step s when every chunk this workgroup's crops belong to has all its crops finished at steps <= s + 1, i.e. the
+    //      chunk's run length T_run = max finish step is covered.  Nobody waits: a workgroup that cannot see the others'
+    //      flags yet just runs further steps, whose outputs are then unused.
+    if (a.chunk_state) {
+      if (tid == 0) {
+        int ex = 1;
+        for (int nb = 0; nb < NB && ex; ++nb) {
+          const int b = b0 + nb;
+          if (b >= a.B) continue;
+          if (s_fin[nb] == a.steps) { ex = 0; break; }
+          const int ch = a.chunk_id[b];
+          if (__hip_atomic_load(&a.chunk_state[2 * ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.chunk_size[ch]) { ex = 0; break; }
+          __threadfence();
+          if (__hip_atomic_load(&a.chunk_state[2 * ch + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > s + 1) ex = 0;
+        }
+        s_exit = ex;
+      }
+      __syncthreads();
+      if (s_exit) break;
+    }
+  }
+  if (tid < NB && b0 + tid < a.B) a.fin_step[b0 + tid] = s_fin[tid];
+}
+
+}  // namespace
+
+int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s) {
+  const size_t ldsz = (size_t)(R * XS + R * H + R * 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_beam_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr = true;
+  }
+  MSOCR_LAUNCH(attn_beam_mfma_kernel, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}

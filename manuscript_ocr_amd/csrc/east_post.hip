@@ -404,10 +404,9 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   int32_t* flag = supp + max_cand;
   int32_t* sbreak = flag + max_cand;
   float* ob = boxes_out + (long)pg * max_cand * 9;
-  __shared__ int nm_s, nk_s, cur_alive, any_changed;
+  __shared__ int nm_s, nk_s, any_changed;
   __shared__ int scan_s[LANMS_T / 64];
   __shared__ unsigned char ch_s[LANMS_T];
-  __shared__ double cur_poly[8];
 
   if (n == 0) {
     if (tid == 0) nbox_out[pg] = 0;
@@ -645,8 +644,8 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
   const int rc = LAUNCH_OK();
   if (dbg) {
     long long* h = (long long*)malloc(sizeof(long long) * 8 * N);
-    hipStreamSynchronize((hipStream_t)stream);
-    hipMemcpy(h, dbg, sizeof(long long) * 8 * N, hipMemcpyDeviceToHost);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemcpy(h, dbg, sizeof(long long) * 8 * N, hipMemcpyDeviceToHost);
     for (int p = 0; p < N && p < 2; ++p) {
       const long long* t = h + p * 8;
       fprintf(stderr, "[lanms dbg] page %d n=%lld nm=%lld  us: sort %.0f specA %.0f fixB %.0f replayC %.0f compactD %.0f nms %.0f\n", p,
@@ -654,7 +653,7 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
               (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0);
     }
     free(h);
-    hipFree(dbg);
+    (void)hipFree(dbg);
   }
   return rc;
 }

@@ -7,4 +7,28 @@
 // C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]  (A [nbatch][M][K], B [nbatch][N][K], C [nbatch][M][N], dense, 16-B aligned).
 __attribute__((visibility("hidden"))) int msocr_internal_gemm_f32_batched(const float* A, const float* B, float* C, long M, int N,
                                                                           int K, int nbatch, hipStream_t s);
+
+// attention decoder arguments shared by trba_kernels.hip (VALU kernels) and attn_beam_mfma.hip (matrix-core beam kernel)
+#include "msocr.h"
+struct AttnArgs {
+  const float* batch_H;
+  const float* proj_H;
+  msocr_attn_weights w;
+  int B, T, V, steps, K;
+  int sos_id, eos_id, blank_id;
+  float temperature;
+  const float* lp;      // [steps] f32 length-penalty factors (beam, alpha > 0) or nullptr
+  float* logits_out;    // greedy: [B][steps][V]; beam: workspace [B][steps][K][V]
+  int32_t* ids_out;     // greedy: [B][steps]
+  int32_t* back;        // beam: [B][steps][K]
+  int32_t* tokv;        // beam: [B][steps][K]
+  int32_t* best_at;     // beam: [B][steps]
+  int32_t* fin_step;    // beam: [B]
+  const int32_t* chunk_id;    // beam, optional: [B] index of the reference chunk (one predict() slice of batch_size crops) of each crop
+  const int32_t* chunk_size;  // [nchunks] crops per chunk
+  int32_t* chunk_state;       // [2*nchunks] zeroed by the caller: {crops finished, max finish step}; enables the early exit
+  int dbg;              // development only: bit mask of phases to skip when timing (results are then meaningless)
+};
+// attn_beam_mfma.hip: beam decode with 4 crops x 8 beams per workgroup on the f32 matrix cores (H == 256, beam <= 8, T <= 64)
+__attribute__((visibility("hidden"))) int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s);
 #endif

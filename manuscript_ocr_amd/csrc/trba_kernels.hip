@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "internal.h"
 #include "msocr.h"
 
 #define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
@@ -255,23 +256,8 @@ extern "C" int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, i
 #define ATT_H 256
 #define ATT_KMAX 8
 
-struct AttnArgs {
-  const float* batch_H;
-  const float* proj_H;
-  msocr_attn_weights w;
-  int B, T, V, steps, K;
-  int sos_id, eos_id, blank_id;
-  float temperature;
-  const float* lp;      // [steps] f32 length-penalty factors (beam, alpha > 0) or nullptr
-  float* logits_out;    // greedy: [B][steps][V]; beam: workspace [B][steps][K][V]
-  int32_t* ids_out;     // greedy: [B][steps]
-  int32_t* back;        // beam: [B][steps][K]
-  int32_t* tokv;        // beam: [B][steps][K]
-  int32_t* best_at;     // beam: [B][steps]
-  int32_t* fin_step;    // beam: [B]
-};
 
-template <int KR, int RPB>
+template <int KR, int RPB, int PF = 4>
 __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, const float* sH, const float* sP, float (*sh)[KR],
                                                     float (*sctx)[KR], float (*sph)[ATT_H], float (*salpha)[64],
                                                     float (*slog)[256], float (&c)[KR], const int* tok, int T, int V) {
@@ -355,7 +341,6 @@ __device__ __forceinline__ void attention_cell_step(const AttnArgs& a, int tid, 
     }
   }
   // weights stream from L2: keep PF 16-byte loads in flight per lane (the FMAs of a k-group run under the next group's loads)
-  constexpr int PF = 4;
   auto gate_pass = [&](const float* __restrict__ wt, float (*x)[KR]) {
     f32x4 wq[PF];
 #pragma unroll
@@ -466,7 +451,7 @@ __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
 // the same instruction stream between the same barriers, so the second half's weight loads hit the lines the first
 // half just pulled into the CU's L1 — the L2 -> L1 weight stream that bounds this kernel is paid once for two rows,
 // at unchanged registers per thread and waves per CU.
-template <int NB, int HB>
+template <int NB, int HB, int PF = 4>
 __global__ __launch_bounds__(256 * HB, (NB == 1 && HB == 1) ? 2 : 1) void attn_beam_kernel(AttnArgs a) {
   constexpr int H = ATT_H, K = ATT_KMAX, KR = NB * K;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // per half: batch_H[NB][T][H] | proj_H[NB][T][H]
@@ -516,7 +501,7 @@ __global__ __launch_bounds__(256 * HB, (NB == 1 && HB == 1) ? 2 : 1) void attn_b
     int tok[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) tok[r] = s_tok[r];
-    attention_cell_step<KR, K>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
+    attention_cell_step<KR, K, PF>(a, tid, sH, sP, sh, sctx, sph, salpha, slog, c, tok, T, V);
     // temperature (true f32 division, model.py:135-137), keep the scaled logits for the trace
     if (tid < V) {
 #pragma unroll
@@ -713,7 +698,8 @@ extern "C" int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, i
 
 extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H, int V,
                                int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
-                               int32_t* fin_step_out, void* workspace, void* stream) {
+                               int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
+                               int32_t* chunk_state_dev, void* stream) {
   if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !fin_step_out || !workspace) return MSOCR_E_ARG;
   if (beam < 1 || beam > ATT_KMAX || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
   AttnArgs a{};
@@ -726,6 +712,7 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
   a.tokv = (int32_t*)p; p += (int64_t)B * steps * beam * 4;
   a.best_at = (int32_t*)p;
   a.fin_step = fin_step_out;
+  if (chunk_id_dev && chunk_size_dev && chunk_state_dev) { a.chunk_id = chunk_id_dev; a.chunk_size = chunk_size_dev; a.chunk_state = chunk_state_dev; }
   // NB = 2 batch rows per workgroup when their encoder rows fit in LDS beside the 68 KB of state (T <= 20), else 1
   // two batch rows per workgroup (two 256-thread halves sharing the weight stream through L1) when both rows' encoder
   // tiles fit in LDS beside 2 x 34 KB of state (T <= 20); MSOCR_BEAM_HB=1 forces one row per workgroup
@@ -734,16 +721,27 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
     const char* e = getenv("MSOCR_BEAM_HB");
     if (e && e[0] == '2' && T <= 20 && B >= 2) HB = 2;
   }
+  // default: the matrix-core kernel (4 crops x 8 beams per workgroup); MSOCR_BEAM_MFMA=0 selects the VALU kernel below
+  static const bool use_mfma = !(getenv("MSOCR_BEAM_MFMA") && getenv("MSOCR_BEAM_MFMA")[0] == '0');
+  a.dbg = getenv("MSOCR_BEAM_DBG") ? atoi(getenv("MSOCR_BEAM_DBG")) : 0;
+  if (use_mfma && HB == 1) return msocr_internal_attn_beam_mfma(a, (hipStream_t)stream);
   const size_t lds = (size_t)2 * HB * T * ATT_H * sizeof(float);
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)attn_beam_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_kernel<1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_kernel<1, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 48 * ATT_H * 4) != hipSuccess ||
         hipFuncSetAttribute((const void*)attn_beam_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 20 * ATT_H * 4) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
+  static const int pf = getenv("MSOCR_BEAM_PF") ? atoi(getenv("MSOCR_BEAM_PF")) : 4;
   if (HB == 2)
     MSOCR_LAUNCH((attn_beam_kernel<1, 2>), dim3((B + 1) / 2), dim3(512), lds, (hipStream_t)stream, a);
+  else if (pf == 8)
+    MSOCR_LAUNCH((attn_beam_kernel<1, 1, 8>), dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+  else if (pf == 16)
+    MSOCR_LAUNCH((attn_beam_kernel<1, 1, 16>), dim3(B), dim3(256), lds, (hipStream_t)stream, a);
   else
     MSOCR_LAUNCH((attn_beam_kernel<1, 1>), dim3(B), dim3(256), lds, (hipStream_t)stream, a);
   return LAUNCH_OK();

@@ -134,22 +134,60 @@ class TRBA:
         return np.stack([resize_and_pad(self._load_rgb(im), self.img_h, self.img_w) for im in images])
 
     # ------------------------------------------------------------------------------------- device path
-    def recognize_start(self, canvases_dev: torch.Tensor, mode="beam", beam_size=8, temperature=1.7, alpha=0.9):
-        """Phase 1 — encode + full-length decode of [N,img_h,img_w,3] u8 device canvases, enqueued on the CURRENT
-        stream without any synchronisation.  Returns a handle for `recognize_finish`."""
+    def _device_batches(self, N, spans, batch_size):
+        """Reference chunks (slices of `batch_size` rows inside each span = one model call of the reference) packed into
+        launches of at most `device_batch` rows that never split a chunk.  -> (bounds [(lo, hi)], per-launch int32 meta
+        = chunk ids of the rows followed by the chunk sizes)."""
+        chunk_of = np.full(N, -1, dtype=np.int64)
+        chunks = []
+        for s0, cnt in (spans if spans is not None else [(0, N)]):
+            for c0 in range(s0, s0 + cnt, batch_size):
+                c1 = min(c0 + batch_size, s0 + cnt)
+                chunk_of[c0:c1] = len(chunks)
+                chunks.append((c0, c1))
+        contiguous = len(chunks) > 0 and chunks[0][0] == 0 and chunks[-1][1] == N and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+        if not contiguous:  # rows outside every span, or spans out of order: no chunk information (all steps run)
+            return [(s, min(s + self.device_batch, N)) for s in range(0, N, self.device_batch)], None
+        bounds, metas, lo, first = [], [], 0, 0
+        for k, (c0, c1) in enumerate(chunks + [(N, N)]):
+            if k == len(chunks) or (c1 - lo > self.device_batch and c0 > lo):
+                ids = chunk_of[lo:c0] - first
+                sizes = np.array([b - a for a, b in chunks[first:k]], dtype=np.int64)
+                bounds.append((lo, c0))
+                metas.append(np.concatenate([ids, sizes]).astype(np.int32))
+                lo, first = c0, k
+        return bounds, metas
+
+    def recognize_start(self, canvases_dev: torch.Tensor, mode="beam", beam_size=8, temperature=1.7, alpha=0.9, spans=None,
+                        batch_size=32):
+        """Phase 1 — encode + decode of [N,img_h,img_w,3] u8 device canvases, enqueued on the CURRENT stream without any
+        synchronisation.  Returns a handle for `recognize_finish`.  `spans`/`batch_size` (the same values `recognize_finish`
+        will get) tell the beam kernel which rows share a reference chunk, so it can stop a chunk where the reference's
+        loop does; without them every row runs all max_length steps (same results)."""
         if mode not in ("greedy", "beam"):
             raise ValueError(f"Unknown mode: {mode}")
         N = canvases_dev.shape[0]
-        parts = []
-        for s in range(0, N, self.device_batch):
-            cv = canvases_dev[s:s + self.device_batch]
+        bounds, metas = self._device_batches(N, spans, batch_size) if mode == "beam" and spans is not None else \
+            ([(s, min(s + self.device_batch, N)) for s in range(0, N, self.device_batch)], None)
+        meta_dev = None
+        if metas is not None:  # ONE small upload, before any encoder work is queued on this stream
+            meta_dev = torch.from_numpy(np.concatenate(metas)).to(self.device)
+        parts, off = [], 0
+        for k, (lo, hi) in enumerate(bounds):
+            cv = canvases_dev[lo:hi]
             batch_H, proj_H = self.model.encode(cv)
             if mode == "greedy":
                 parts.append(self.model.greedy(batch_H, proj_H, self.max_length, self.sos_id, self.eos_id, self.blank_id))
             else:
+                chunks = None
+                if meta_dev is not None:
+                    nrows, nch = hi - lo, len(metas[k]) - (hi - lo)
+                    chunks = (meta_dev[off:off + nrows], meta_dev[off + nrows:off + nrows + nch],
+                              torch.zeros((2 * nch,), dtype=torch.int32, device=self.device))
+                    off += nrows + nch
                 parts.append(self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
-                                             self.blank_id))
-        return {"parts": parts, "N": N, "mode": mode, "beam": beam_size}
+                                             self.blank_id, chunks))
+        return {"parts": parts, "N": N, "mode": mode, "beam": beam_size, "bounds": bounds}
 
     def recognize_finish(self, handle, batch_size=32, spans=None, return_logits=False):
         """Phases 2-3 — derive the reference's per-chunk run lengths, back-track (beam) and reduce confidences.
@@ -179,8 +217,8 @@ class TRBA:
                     trun[c0:c1] = fin_h[c0:c1].max()
         trun_dev = torch.from_numpy(trun).to(self.device)
         ids_out, conf_out, logit_out = [], [], []
-        for k, s in enumerate(range(0, N, self.device_batch)):
-            B = min(self.device_batch, N - s)
+        for k, (s, hi) in enumerate(handle["bounds"]):
+            B = hi - s
             tr = trun_dev[s:s + B]
             if mode == "greedy":
                 lg, ids = parts[k]
@@ -202,7 +240,9 @@ class TRBA:
     def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
                            spans=None, return_logits=False):
         """canvases [N,img_h,img_w,3] u8 on device -> (ids [N,steps] i32, t_run [N] i32, conf [N] f32[, logits]) on host."""
-        return self.recognize_finish(self.recognize_start(canvases_dev, mode, beam_size, temperature, alpha), batch_size, spans, return_logits)
+        return self.recognize_finish(self.recognize_start(canvases_dev, mode, beam_size, temperature, alpha,
+                                                          spans if spans is not None else [(0, canvases_dev.shape[0])], batch_size),
+                                     batch_size, spans, return_logits)
 
     def texts(self, ids, trun) -> List[str]:
         """decode_tokens (transforms.py:196-206) over the first t_run ids of every row, vectorised: the text ends at the

@@ -165,8 +165,10 @@ class TrbaNet:
                                               ops._stream()), "attn_greedy")
         return logits, ids
 
-    def beam(self, batch_H, proj_H, max_len, beam_size, alpha, temperature, sos_id, eos_id, blank_id):
-        """Runs all `max_len` steps; returns (workspace, fin_step [B] i32) for `beam_finalize`."""
+    def beam(self, batch_H, proj_H, max_len, beam_size, alpha, temperature, sos_id, eos_id, blank_id, chunks=None):
+        """Returns (workspace, fin_step [B] i32, lp) for `beam_finalize`.  Runs all `max_len` steps, or — given
+        chunks = (chunk_id [B] i32, chunk_size [nchunks] i32, chunk_state [2*nchunks] i32 zeros), all on the device — only
+        as many as the reference's own loop would (it breaks once every beam of the chunk is finished, model.py:215)."""
         B, T, H = batch_H.shape
         steps = max_len
         nbytes = nat.lib().msocr_attn_beam_workspace_bytes(B, steps, beam_size, self.V)
@@ -185,7 +187,9 @@ class TrbaNet:
             lp = self._lp_cache[key]
         nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
                                             beam_size, lp.data_ptr() if lp is not None else None, float(temperature), sos_id, eos_id,
-                                            -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(), ops._stream()),
+                                            -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(),
+                                            chunks[0].data_ptr() if chunks else None, chunks[1].data_ptr() if chunks else None,
+                                            chunks[2].data_ptr() if chunks else None, ops._stream()),
                   "attn_beam")
         return ws, fin, lp
 

@@ -216,3 +216,25 @@ def test_vectorised_texts_equal_decode_tokens():
         exp = [decode_tokens(ids[j, : int(trun[j])], itos, 0, 2, blank) for j in range(200)]
         assert TRBA.texts(stub, ids, trun) == exp
     assert TRBA.texts(stub, np.zeros((0, 5), np.int32), np.zeros((0,), np.int32)) == []
+
+
+def test_device_batches_never_split_a_reference_chunk():
+    """TRBA._device_batches: launches of <= device_batch rows aligned to the reference's chunks (slices of batch_size rows
+    inside a span); per-launch metadata = chunk id of every row + chunk sizes; no chunk information when rows are uncovered."""
+    import types
+
+    from manuscript_ocr_amd.recognizers import TRBA
+    stub = types.SimpleNamespace(device_batch=100)
+    bounds, metas = TRBA._device_batches(stub, 118, [(0, 70), (70, 45), (115, 3)], 32)
+    assert bounds == [(0, 70), (70, 118)]
+    assert metas[0][70:].tolist() == [32, 32, 6] and metas[1][48:].tolist() == [32, 13, 3]
+    assert metas[0][:70].tolist() == [0] * 32 + [1] * 32 + [2] * 6
+    assert metas[1][:48].tolist() == [0] * 32 + [1] * 13 + [2] * 3
+    bounds, metas = TRBA._device_batches(stub, 250, [(0, 250)], 32)
+    assert bounds == [(0, 96), (96, 192), (192, 250)] and [len(m) for m in metas] == [99, 99, 60]
+    for (lo, hi), m in zip(bounds, metas):
+        ids, sizes = m[: hi - lo], m[hi - lo:]
+        assert np.array_equal(np.bincount(ids), sizes) and sizes.max() <= 32
+    assert TRBA._device_batches(stub, 10, [(5, 5)], 32) == ([(0, 10)], None)
+    big = types.SimpleNamespace(device_batch=8)   # a chunk larger than a launch is kept whole
+    assert TRBA._device_batches(big, 40, [(0, 40)], 32)[0] == [(0, 32), (32, 40)]

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
-from oracle import trba_model as otm
+from manuscript_ocr_amd import synth
 
 net = TrbaNet(synth.trba_state_dict(194, 256, seed=1), 194, 256, torch.float32)
 for B in (960, 2048):
