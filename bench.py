@@ -195,6 +195,7 @@ def main():
                 pipe.serialize_streams = a.serialize_streams
             iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1, _, _ in prof)
             fl = float(sum(f for _, _, f, _ in prof))
+            instrumented.executed = float(sum(t[4] for _, _, _, t in prof))
             dur = np.array([e - s for s, e in iv])
             union, cs, ce = 0.0, iv[0][0], iv[0][1]
             for s_, e_ in iv[1:]:
@@ -211,10 +212,16 @@ def main():
         prof, fl, dur, union = instrumented(a.serialize_streams)
         tf = fl / (union * 1e-3) / 1e12
         res["roofline"] = {
-            "kernel": "conv_igemm_kernel (every implicit-GEMM launch of a step; achieved = algorithmic FLOP / time in which "
-                      "at least one such launch is executing, sub-batch streams overlapping as in the timed region)",
+            "kernel": "convolution stage = every msocr_conv2d / msocr_conv3x3_winograd call of a step (conv_igemm_kernel, plus the "
+                      "two Winograd transform kernels around its 16-GEMM launch); achieved = ALGORITHMIC direct-convolution FLOP "
+                      "(2*MACs, SURVEY.md 8d) / time in which at least one such call is executing, sub-batch streams overlapping as "
+                      "in the timed region.  Winograd F(2x2,3x3) executes 2.25x fewer matrix FLOPs than the algorithmic count on "
+                      "the 3x3/1/1 layers, so `achieved` may approach or pass the MFMA peak; `executed_mfma_tflops` is what the "
+                      "matrix pipes really run",
             "bound": "mfma",
             "achieved": tf,
+            "executed_mfma_tflops": instrumented.executed / (union * 1e-3) / 1e12,
+            "executed_frac_of_peak": instrumented.executed / (union * 1e-3) / 1e12 / peak,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": tf / peak,
@@ -233,7 +240,7 @@ def main():
         if os.environ.get("MSOCR_DUMP_CONV"):
             agg = {}
             for (e0, e1, f, tag) in prof:
-                a_ = agg.setdefault(tag, [0, 0.0, 0.0])
+                a_ = agg.setdefault(tag[:4], [0, 0.0, 0.0])
                 a_[0] += 1
                 a_[1] += e0.elapsed_time(e1)
                 a_[2] += f
@@ -251,10 +258,10 @@ def main():
 
 
 def pmc_traffic():
-    """HBM bytes per step of the conv launches from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    """HBM bytes per step of the convolution stage (conv_igemm_kernel + Winograd transforms) from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     rocprofv3 --pmc passes of this same command; bench.py cannot run the profiler on itself, so the committed
     measurement is reported, or null when absent / not for this workload)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_bytes_per_step"])

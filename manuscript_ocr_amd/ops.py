@@ -111,10 +111,11 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     else:
         rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
         nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
-    if prof is not None:  # FLOPs are ALGORITHMIC (direct-convolution 2*MACs) for both paths
+    if prof is not None:  # FLOPs are ALGORITHMIC (direct-convolution 2*MACs) for both paths; tag[4] = FLOPs the MFMAs execute
         e1.record()
+        executed = 2.0 * 16 * N * ((Ho + 1) // 2) * ((Wo + 1) // 2) * Cin * Cout if use_wino else 2.0 * N * Ho * Wo * Cout * KH * KW * Cin
         prof.append((e0, e1, 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin),
-                     (N * Ho * Wo, Cout, KH * KW * Cin, "winograd" if use_wino else "direct")))
+                     (N * Ho * Wo, Cout, KH * KW * Cin, "winograd" if use_wino else "direct", executed)))
     return out
 
 
