@@ -160,3 +160,52 @@ def test_trba_bf16_cnn_close(env):
     batch_H, _ = net.encode(cd)
     err = np.abs(batch_H.cpu().numpy() - ref).max()
     assert err < 0.15 * max(1.0, np.abs(ref).max()), err
+
+
+def test_beam_kernels_agree_and_early_exit_changes_nothing(env, monkeypatch):
+    """Matrix-core beam kernel (default) vs the VALU kernel (MSOCR_BEAM_MFMA=0): same ids / finish steps, logits within 1e-3 of
+    the largest logit; and the chunk-level early exit (rows grouped like the reference's batch_size chunks) leaves every
+    output the finalize step reads (t < chunk run length) bit-identical to the run over all steps."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
+    net = TrbaNet(synth.trba_state_dict_confident(194, 256, seed=11), 194, 256, torch.float32)
+    B, K, steps = 70, 8, 25
+    cd = torch.from_numpy(synth.synth_crops(21, B, 32, 100)).cuda()
+    batch_H, proj_H = net.encode(cd)
+
+    def run(chunks=None):
+        ws, fin, _ = net.beam(batch_H, proj_H, steps, K, 0.9, 1.7, 1, 2, None, chunks)
+        return ws, fin.cpu().numpy()
+
+    def finalize(ws, fin_h, sizes):
+        trun, o = np.empty(B, dtype=np.int32), 0
+        for sz in sizes:
+            trun[o:o + sz] = fin_h[o:o + sz].max()
+            o += sz
+        lg, ids = net.beam_finalize(ws, B, steps, K, torch.from_numpy(trun).cuda())
+        return trun, lg.cpu().numpy(), ids.cpu().numpy()
+
+    sizes = [32, 32, 6]
+    ws_m, fin_m = run()
+    trun, lg_m, ids_m = finalize(ws_m, fin_m, sizes)
+    assert trun.max() < steps, "fixture must finish early for the early-exit check to mean anything"
+    # (1) VALU kernel
+    monkeypatch.setenv("MSOCR_BEAM_MFMA", "0")
+    ws_v, fin_v = run()
+    monkeypatch.delenv("MSOCR_BEAM_MFMA")
+    _, lg_v, ids_v = finalize(ws_v, fin_v, sizes)
+    assert np.array_equal(fin_m, fin_v) and np.array_equal(ids_m, ids_v)
+    for b in range(B):
+        t = trun[b]
+        assert np.abs(lg_m[b, :t] - lg_v[b, :t]).max() < 1e-3 * max(1.0, np.abs(lg_v[b, :t]).max())
+    # (2) early exit
+    ids_c = torch.from_numpy(np.repeat(np.arange(3), sizes).astype(np.int32)).cuda()
+    size_c = torch.tensor(sizes, dtype=torch.int32).cuda()
+    state = torch.zeros(6, dtype=torch.int32).cuda()
+    ws_e, fin_e = run((ids_c, size_c, state))
+    _, lg_e, ids_e = finalize(ws_e, fin_e, sizes)
+    st = state.cpu().numpy()
+    assert np.array_equal(fin_e, fin_m) and st[0::2].tolist() == sizes and st[1::2].tolist() == [int(trun[0]), int(trun[32]), int(trun[64])]
+    assert np.array_equal(ids_e, ids_m)
+    for b in range(B):
+        assert np.array_equal(lg_e[b, :trun[b]], lg_m[b, :trun[b]])
