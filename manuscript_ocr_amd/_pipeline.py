@@ -94,6 +94,16 @@ class Pipeline:
     # ------------------------------------------------------------------------------------- API
     def predict(self, image: Union[str, np.ndarray, Image.Image], recognize_text: bool = True, vis: bool = False,
                 profile: bool = False):
+        if (isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA) and recognize_text and not profile
+                and getattr(self, "native_fast_path", True)):
+            # both plugins are this package's: same result through the device path (crops cut, resized and padded on the
+            # device from the uploaded page, one recogniser pass) — tests/test_gpu_pipeline.py pins batch == per-page
+            image_array = read_image(image)
+            page = self.predict_batch([image_array])[0]
+            if vis:
+                pil = image if isinstance(image, Image.Image) else Image.fromarray(image_array)
+                return page, visualize_page(pil, page, show_order=True)
+            return page
         start = time.time()
         t0 = time.time()
         page = self._page_of(self.detector.predict(image, vis=False, profile=profile))

@@ -120,7 +120,12 @@ def test_predict_batch_equals_per_page_predict(gpu):
     pipe = Pipeline(detector=det, recognizer=rec)
     pages = [synth.synth_page(s, H, W)[0] for s in (1, 2, 3)]
     a = pipe.predict_batch(pages)
+    pipe.native_fast_path = False       # the generic plugin path: detector.predict + host crops + recognizer.predict
     b = [pipe.predict(p) for p in pages]
+    pipe.native_fast_path = True        # default: predict() itself goes through the device path
+    c = [pipe.predict(p) for p in pages]
+    assert [[(w.polygon, w.text, w.recognition_confidence) for w in p.blocks[0].words] for p in c] == \
+           [[(w.polygon, w.text, w.recognition_confidence) for w in p.blocks[0].words] for p in a]
     assert sum(len(p.blocks[0].words) for p in a) > 0, "random-weight maps produced no boxes; lower score_thresh"
     for pa, pb in zip(a, b):
         assert [w.polygon for w in pa.blocks[0].words] == [w.polygon for w in pb.blocks[0].words]
