@@ -75,10 +75,15 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
-            # the in-tree build product is missing (fresh checkout): compile it once, in-tree, for gfx950
+            # the in-tree build product is missing (fresh checkout): compile it once, in-tree, for gfx950.  One process per
+            # GPU may get here at the same time (torchrun): serialise on a lock file, the others then find the library.
+            import fcntl
             import subprocess
             try:
-                subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"])
+                with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    if not os.path.exists(LIB_PATH):
+                        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"])
             except Exception as e:  # fall through to the loud failure below
                 print(f"[manuscript_ocr_amd] building libmsocr.so failed: {e}")
         if not os.path.exists(LIB_PATH):
