@@ -52,6 +52,7 @@ class EAST:
         precision: str = "fp32",
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         max_candidates: int = 65536,
+        use_graphs: bool = False,
     ):
         self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
         if not str(self.device).startswith("cuda") or not torch.cuda.is_available():
@@ -88,6 +89,8 @@ class EAST:
         self.anomaly_sigma_threshold = anomaly_sigma_threshold
         self.anomaly_min_box_count = anomaly_min_box_count
         self.max_candidates = max_candidates
+        self.use_graphs = bool(use_graphs)  # hipGraph replay of the static detect sequence in detect_start (BASELINE configs[3])
+        self._graphs: Dict[Any, Dict[str, Any]] = {}
         if abs(1.0 / score_geo_scale - 4.0) > 1e-9:
             raise ValueError("the network emits maps at 1/4 resolution (east.py:126-127): score_geo_scale must be 0.25")
 
@@ -141,37 +144,69 @@ class EAST:
 
     # ------------------------------------------------------------------------------------- API
     def detect_start(self, pages_dev: torch.Tensor, maps_override=None):
-        """Enqueue resize + network + decode + LANMS for [N,h,w,3] u8 device pages on the CURRENT stream; no sync."""
-        return self.detect_device(pages_dev, maps_override)
+        """Enqueue resize + network + decode + LANMS for [N,h,w,3] u8 device pages on the CURRENT stream; no sync.
+
+        With `use_graphs` the whole sequence (~110 launches, static shapes) is captured once per input shape into a
+        hipGraph and replayed: the page bytes are copied into the instance's static input buffer, the outputs live in
+        the graph's private pool until `detect_finish` has read them.  The first call of a shape runs eagerly (lazy
+        one-time kernel attributes must not fall into a capture); an instance still in flight is never replayed — a
+        second one is captured (two batches in flight = two instances per group)."""
+        if not self.use_graphs or ops.PROFILE is not None:
+            return self.detect_device(pages_dev, maps_override) + (None,)
+        key = (tuple(pages_dev.shape), None if maps_override is None else (maps_override[0].data_ptr(), maps_override[1].data_ptr()))
+        pool = self._graphs.setdefault(key, {"warm": False, "inst": []})
+        if not pool["warm"]:
+            pool["warm"] = True
+            return self.detect_device(pages_dev, maps_override) + (None,)
+        inst = next((i for i in pool["inst"] if not i["busy"]), None)
+        if inst is None:
+            if len(pool["inst"]) >= 4:
+                return self.detect_device(pages_dev, maps_override) + (None,)
+            for _ in range(2 if not pool["inst"] else 1):  # the first capture of a shape makes TWO instances: consecutive
+                inp = torch.empty_like(pages_dev)          # batches overlap (submit i+1 before collect i), so both are needed
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.detect_device(inp, maps_override)
+                pool["inst"].append({"graph": graph, "inp": inp, "out": out, "busy": False})
+            inst = pool["inst"][-1]
+        inst["busy"] = True
+        inst["inp"].copy_(pages_dev, non_blocking=True)
+        inst["graph"].replay()
+        return inst["out"] + (inst,)
 
     def detect_finish(self, handle, imgs, vis=False, profile=False, return_maps=False, sort_reading_order=False):
         """Wait for `handle` (from detect_start), then the host tail (infer.py:340-390) -> list of result dicts."""
-        t0 = time.time()
-        score, geo, boxes, nbox, counts = handle
-        nbox_h = nbox.cpu().numpy()
-        counts_h = counts.cpu().numpy()
-        if np.any(counts_h < 0):
-            raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
-        boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
-        if profile:
-            print(f"  Model inference + decode + NMS (device wait): {time.time() - t0:.3f}s")
-            print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
-        t_dev = time.time() - t0
-        results = []
-        for n, img in enumerate(imgs):
-            quads = self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
-            words = self._words(quads)
-            if sort_reading_order and words:
-                words = self._sort_words(words)
-            page = Page(blocks=[Block(words=words)])
-            results.append({
-                "page": page,
-                "vis_image": visualize_page(img, page, show_order=False) if vis else None,
-                "score_map": score[n].cpu().numpy() if return_maps else None,
-                "geo_map": geo[n].permute(2, 0, 1).contiguous().cpu().numpy() if return_maps else None,
-            })
-        self.last_profile = {"device_wait": t_dev, "host_tail": time.time() - t0 - t_dev}
-        return results
+        inst = handle[5]
+        try:
+            t0 = time.time()
+            score, geo, boxes, nbox, counts, _ = handle
+            nbox_h = nbox.cpu().numpy()
+            counts_h = counts.cpu().numpy()
+            if np.any(counts_h < 0):
+                raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
+            boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
+            if profile:
+                print(f"  Model inference + decode + NMS (device wait): {time.time() - t0:.3f}s")
+                print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
+            t_dev = time.time() - t0
+            results = []
+            for n, img in enumerate(imgs):
+                quads = self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
+                words = self._words(quads)
+                if sort_reading_order and words:
+                    words = self._sort_words(words)
+                page = Page(blocks=[Block(words=words)])
+                results.append({
+                    "page": page,
+                    "vis_image": visualize_page(img, page, show_order=False) if vis else None,
+                    "score_map": score[n].cpu().numpy() if return_maps else None,
+                    "geo_map": geo[n].permute(2, 0, 1).contiguous().cpu().numpy() if return_maps else None,
+                })
+            self.last_profile = {"device_wait": t_dev, "host_tail": time.time() - t0 - t_dev}
+            return results
+        finally:
+            if inst is not None:
+                inst["busy"] = False  # every output of the graph instance has been copied out (or the call failed)
 
     def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
                       sort_reading_order=False, _maps_override=None, _pages_dev=None) -> List[Dict[str, Any]]:

@@ -66,3 +66,29 @@ def test_east_forward_bf16_close(setup):
     es = np.abs(score.cpu().numpy() - rs).max()
     eg = np.abs(geo.cpu().numpy() - rg).max() / max(np.abs(rg).max(), 1.0)
     assert es < 0.05 and eg < 0.05, (es, eg)
+
+
+def test_hipgraph_replay_equals_eager(setup):
+    """EAST(use_graphs=True): the captured detect sequence (network + decode + LANMS), replayed on fresh page bytes, returns the
+    same maps and boxes as the eager launches; two handles in flight use two graph instances."""
+    from manuscript_ocr_amd.detectors import EAST
+    sd, _ = setup
+    H, W = 128, 160
+    eager = EAST(state_dict=sd, target_size=(W, H), device="cuda", score_thresh=0.5)
+    graph = EAST(state_dict=sd, target_size=(W, H), device="cuda", score_thresh=0.5, use_graphs=True)
+    for rnd in range(4):  # 1st call warm-up (eager), 2nd captures + replays, later ones replay
+        pages = [_page(10 * rnd + k, H, W) for k in range(2)]
+        a = eager.predict_batch(pages, return_maps=True)
+        b = graph.predict_batch(pages, return_maps=True)
+        for ra, rb in zip(a, b):
+            assert np.array_equal(ra["score_map"], rb["score_map"]) and np.array_equal(ra["geo_map"], rb["geo_map"])
+            assert [w.polygon for w in ra["page"].blocks[0].words] == [w.polygon for w in rb["page"].blocks[0].words]
+    pool = next(iter(graph._graphs.values()))
+    assert pool["warm"] and len(pool["inst"]) == 2 and not any(i["busy"] for i in pool["inst"])
+    dev = torch.from_numpy(np.stack([_page(k, H, W) for k in range(2)])).cuda()
+    h1, h2 = graph.detect_start(dev), graph.detect_start(dev)   # two batches in flight -> two instances
+    assert h1[5] is not None and h2[5] is not None and h1[5] is not h2[5] and len(pool["inst"]) == 2
+    r1 = graph.detect_finish(h1, [_page(0, H, W)] * 2)
+    r2 = graph.detect_finish(h2, [_page(0, H, W)] * 2)
+    assert [w.polygon for w in r1[0]["page"].blocks[0].words] == [w.polygon for w in r2[0]["page"].blocks[0].words]
+    assert not any(i["busy"] for i in pool["inst"])
