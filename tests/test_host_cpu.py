@@ -238,3 +238,33 @@ def test_device_batches_never_split_a_reference_chunk():
     assert TRBA._device_batches(stub, 10, [(5, 5)], 32) == ([(0, 10)], None)
     big = types.SimpleNamespace(device_batch=8)   # a chunk larger than a launch is kept whole
     assert TRBA._device_batches(big, 40, [(0, 40)], 32)[0] == [(0, 32), (32, 40)]
+
+
+def test_oracle_is_only_a_checker():
+    """The CPU restatement under oracle/ is test infrastructure: the product package never imports it, bench.py only inside
+    its cpu_baseline leg, __graft_entry__ only inside smoke()."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(tree):
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node)
+            elif isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node)
+        return hits
+
+    for dirpath, _, files in os.walk(os.path.join(root, "manuscript_ocr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, f)).read())
+                assert not oracle_imports(tree), f"{f} imports the oracle"
+    for fname, allowed in (("bench.py", {"cpu_baseline"}), ("__graft_entry__.py", {"smoke"})):
+        tree = ast.parse(open(os.path.join(root, fname)).read())
+        inside = set()
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            if oracle_imports(fn):
+                inside.add(fn.name)
+        assert inside <= allowed and len(oracle_imports(tree)) == sum(len(oracle_imports(fn)) for fn in ast.walk(tree)
+                                                                      if isinstance(fn, ast.FunctionDef) and fn.name in allowed), (fname, inside)
