@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
 
   for (int s = 0; s < a.steps; ++s) {
     // ---- (a) ph[r][j] = h2h_b[j] + sum_k h[r][k] * h2h_wt[k][j]
-    if (!(a.dbg & 1)) {
+    {
       f32x16 acc;
       const float bj = a.w.h2h_b[ju];
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
     __syncthreads();
     // ---- (b) e[r][t] = sum_j score_w[j] * tanh(proj_H[crop][t][j] + ph[r][j]) : one wave per (crop, t) group — the
     //      proj_H row is read once for the crop's 8 beams; the rows of up to GB groups are in flight together
-    if (!(a.dbg & 2)) {
+    {
       constexpr int GB = 4;
       float sw[H / 64];
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
     }
     __syncthreads();
     // ---- (d) ctx[r][j] = sum_t alpha[r][t] * batch_H[crop(r)][t][j] : thread = (j, half of the crops)
-    if (!(a.dbg & 4)) {
+    {
       const int j = tid & 255, ch = tid >> 8;
 #pragma unroll
       for (int n2 = 0; n2 < NB / 2; ++n2) {
@@ -268,10 +268,8 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g][e] = b4[g] + t4[g];
       }
-      if (!(a.dbg & 8)) {
-        mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
-        mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
-      }
+      mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+      mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
       __syncthreads();  // every wave has read the old h
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -288,7 +286,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       const float bv = vok ? a.w.gen_b[ju] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = bv;
-      if (32 * wv < V && !(a.dbg & 16)) mfma_cols32(sX, H, a.w.gen_wt, V, ju, vok, r32, half, acc);
+      if (32 * wv < V) mfma_cols32(sX, H, a.w.gen_wt, V, ju, vok, r32, half, acc);
       if (vok) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
     // ---- (h) top-K of the K*V candidates of every crop: ONE wave per crop (lane owns v = lane + 64 i), the K rounds of
     //      arg-max + winner removal need no workgroup barrier.  Order: larger value, then smaller flat index beam*V + v.
     const float lp = a.lp ? a.lp[s] : 1.0f;
-    if (!(a.dbg & 32) && wv < NB) {
+    if (wv < NB) {
       const int nb = wv;
       constexpr int VI = 4;  // V <= 256
       float cv[VI][KB8];
@@ -410,7 +408,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       }
     }
     // ---- (j) permute beam state by src within every crop: c through sbuf (logits are consumed), h through registers
-    if (!(a.dbg & 64)) {
+    {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = c[e];
       const int j = tid & 255, ch = tid >> 8;

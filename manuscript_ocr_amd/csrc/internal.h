@@ -27,7 +27,6 @@ struct AttnArgs {
   const int32_t* chunk_id;    // beam, optional: [B] index of the reference chunk (one predict() slice of batch_size crops) of each crop
   const int32_t* chunk_size;  // [nchunks] crops per chunk
   int32_t* chunk_state;       // [2*nchunks] zeroed by the caller: {crops finished, max finish step}; enables the early exit
-  int dbg;              // development only: bit mask of phases to skip when timing (results are then meaningless)
 };
 // attn_beam_mfma.hip: beam decode with 4 crops x 8 beams per workgroup on the f32 matrix cores (H == 256, beam <= 8, T <= 64)
 __attribute__((visibility("hidden"))) int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s);

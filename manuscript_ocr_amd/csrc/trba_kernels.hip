@@ -724,7 +724,6 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
   // default: the matrix-core kernel (4 crops x 8 beams per workgroup); MSOCR_BEAM_MFMA=0 selects the VALU kernel below
   const char* em = getenv("MSOCR_BEAM_MFMA");  // read per call: tests switch kernels inside one process
   const bool use_mfma = !(em && em[0] == '0');
-  a.dbg = getenv("MSOCR_BEAM_DBG") ? atoi(getenv("MSOCR_BEAM_DBG")) : 0;
   if (use_mfma && HB == 1) return msocr_internal_attn_beam_mfma(a, (hipStream_t)stream);
   const size_t lds = (size_t)2 * HB * T * ATT_H * sizeof(float);
   static bool attr = false;

@@ -209,3 +209,20 @@ def test_beam_kernels_agree_and_early_exit_changes_nothing(env, monkeypatch):
     assert np.array_equal(ids_e, ids_m)
     for b in range(B):
         assert np.array_equal(lg_e[b, :trun[b]], lg_m[b, :trun[b]])
+
+
+def test_small_device_batches_give_the_same_results(env):
+    """Launch splitting (device_batch) is invisible: 120 crops in launches of <= 50 rows (aligned to the reference's 32-row
+    chunks: 32 + 32 + 32 + 24) == one launch, in both modes."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.recognizers import TRBA
+    sd = synth.trba_state_dict_confident(194, 256, seed=5)
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    one = TRBA(state_dict=sd, config=cfg, device="cuda")
+    many = TRBA(state_dict=sd, config=cfg, device="cuda", device_batch=50)
+    crops = list(synth.synth_crops(31, 120, 32, 100))
+    for mode in ("beam", "greedy"):
+        a, b = one.predict(crops, mode=mode), many.predict(crops, mode=mode)
+        assert [r["text"] for r in a] == [r["text"] for r in b]
+        np.testing.assert_allclose([r["confidence"] for r in a], [r["confidence"] for r in b], rtol=0, atol=1e-6)
+    assert many._device_batches(120, [(0, 120)], 32)[0] == [(0, 32), (32, 64), (64, 96), (96, 120)]
