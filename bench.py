@@ -83,6 +83,8 @@ def main():
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
     if rec is not None and os.environ.get("MSOCR_DEVICE_BATCH"):
         rec.device_batch = int(os.environ["MSOCR_DEVICE_BATCH"])
+    if pipe is not None and os.environ.get("MSOCR_UPLOAD_ON_REC"):
+        pipe.upload_on_det_stream = False
     if pipe is not None and a.serialize_streams:
         pipe.serialize_streams = True
 

@@ -180,6 +180,15 @@ int msocr_seq_confidence(const float* logits, const int32_t* ids, const int32_t*
 int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32_t* desc_dev,
                           const int32_t* desc_host, int M, int img_h, int img_w, uint8_t* canvases, void* stream);
 
+/* HOST function (plain C++, all pointers host memory): reading order of a page's word boxes, i.e. the Python glue between
+ * detector and recogniser: resolve_intersections + sort_boxes_reading_order(+_with_resolutions)
+ * (detectors/_east/utils.py:500-644) and the "first word with an equal box" re-match of _pipeline.py:113-121, with the
+ * reference's integer / double arithmetic.  boxes_host [n][4] int32 (x_min, y_min, x_max, y_max);
+ * order_out_host [n] int32: entry k = index of the input box at position k of the reading order (duplicates as the
+ * reference's dict semantics produce them). */
+int msocr_reading_order_host(const int32_t* boxes_host, int n, double y_tol_ratio, double x_gap_ratio,
+                             int32_t* order_out_host);
+
 /* f32 <-> bf16 / layout helpers */
 int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int W, int dtype, void* out, int64_t out_ld,
                            void* stream);

@@ -35,6 +35,16 @@ def _gc_paused():
             gc.enable()
 
 
+def _reading_order(aabbs_i32):
+    """Indices of the words in reading order: sort_boxes_reading_order_with_resolutions + the reference's "first word with an
+    equal box" re-match (_pipeline.py:113-121), evaluated by the host helper msocr_reading_order_host (same arithmetic)."""
+    from . import _native as nat
+    boxes = np.ascontiguousarray(aabbs_i32, dtype=np.int32)
+    order = np.empty(len(boxes), dtype=np.int32)
+    nat.check(nat.lib().msocr_reading_order_host(boxes.ctypes.data, len(boxes), 0.6, float("inf"), order.ctypes.data), "reading_order_host")
+    return order.tolist()
+
+
 def _word_aabb(word):
     poly = np.array(word.polygon, dtype=np.int32)  # float -> int32 truncation (reference :106)
     x_min, y_min = np.min(poly, axis=0)
@@ -147,10 +157,7 @@ class Pipeline:
             polys = np.array([w.polygon for w in block.words], dtype=np.float64).astype(np.int32)
             mins, maxs = polys.min(axis=1), polys.max(axis=1)
             aabbs = [(a[0], a[1], b[0], b[1]) for a, b in zip(mins, maxs)]
-            first = {}
-            for k, bx in enumerate(aabbs):  # "first equal word wins" of the reference's O(n^2) re-match (:113-121)
-                first.setdefault(tuple(int(v) for v in bx), k)
-            order = [first[tuple(int(v) for v in bx)] for bx in sort_boxes_reading_order_with_resolutions(aabbs)]
+            order = _reading_order(np.concatenate([mins, maxs], axis=1))
             old_words = block.words
             block.words = [old_words[k] for k in order]
             for k in order:
@@ -275,8 +282,15 @@ class Pipeline:
                                     grp["spans"].append([n0, c])
                                     n0 += c
                             if len(desc):
-                                canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w)
-                                grp["handle"] = rec.recognize_start(canv, spans=[tuple(s) for s in grp["spans"] if s[1] > 0])
+                                spans = [tuple(s) for s in grp["spans"] if s[1] > 0]
+                                up = dst if getattr(self, "upload_on_det_stream", True) else st
+                                with torch.cuda.stream(up):  # the two small blocking uploads ride the high-priority stream
+                                    desc_dev = torch.from_numpy(desc.astype("int32", copy=False)).to(det.device)
+                                    prepared = rec.prepare_chunks(len(desc), spans)
+                                if st is not up:
+                                    st.wait_stream(up)
+                                canv = ops.crop_resize_pad(pages_dev, desc, rec.img_h, rec.img_w, desc_dev=desc_dev)
+                                grp["handle"] = rec.recognize_start(canv, spans=spans, prepared=prepared)
                         tm["crop+enqueue"] += time.perf_counter() - t0
                     else:
                         for pi, r in enumerate(res):

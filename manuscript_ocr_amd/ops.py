@@ -279,14 +279,18 @@ def crop_descriptors(boxes, page_ids, page_hw, img_h, img_w):
     return np.asarray(desc, dtype=np.int32).reshape(-1, 8), np.asarray(keep, dtype=bool)
 
 
-def crop_resize_pad(pages_u8, desc_host, img_h, img_w):
-    """pages [N,H,W,3] u8 device, desc_host int32 [M,8] (numpy) -> canvases [M,img_h,img_w,3] u8 device."""
+def crop_resize_pad(pages_u8, desc_host, img_h, img_w, desc_dev=None):
+    """pages [N,H,W,3] u8 device, desc_host int32 [M,8] (numpy) -> canvases [M,img_h,img_w,3] u8 device.
+    desc_dev: the same descriptors already on the device (uploaded by the caller on another stream)."""
     _need_cuda(pages_u8)
     N, H, W, C = pages_u8.shape
     assert C == 3 and pages_u8.dtype == torch.uint8 and pages_u8.is_contiguous()
     M = len(desc_host)
     desc_host = desc_host.astype("int32", copy=False)
-    desc_dev = torch.from_numpy(desc_host).to(pages_u8.device)
+    if desc_dev is None:
+        desc_dev = torch.from_numpy(desc_host).to(pages_u8.device)
+    else:
+        desc_dev.record_stream(torch.cuda.current_stream())
     out = torch.empty((M, img_h, img_w, 3), dtype=torch.uint8, device=pages_u8.device)
     nat.check(nat.lib().msocr_crop_resize_pad(pages_u8.data_ptr(), N, H, W, desc_dev.data_ptr(), desc_host.ctypes.data, M, img_h, img_w,
                                               out.data_ptr(), _stream()), "crop_resize_pad")

@@ -158,8 +158,16 @@ class TRBA:
                 lo, first = c0, k
         return bounds, metas
 
+    def prepare_chunks(self, N, spans, batch_size=32):
+        """Chunk metadata of `recognize_start` for N rows, uploaded on the CURRENT stream (one small blocking copy).  Callers
+        that pipeline several streams do this on a high-priority stream and pass the result as `prepared=` so the copy does
+        not queue behind the recogniser work of other groups."""
+        bounds, metas = self._device_batches(N, spans, batch_size)
+        meta_dev = torch.from_numpy(np.concatenate(metas)).to(self.device) if metas is not None else None
+        return bounds, metas, meta_dev
+
     def recognize_start(self, canvases_dev: torch.Tensor, mode="beam", beam_size=8, temperature=1.7, alpha=0.9, spans=None,
-                        batch_size=32):
+                        batch_size=32, prepared=None):
         """Phase 1 — encode + decode of [N,img_h,img_w,3] u8 device canvases, enqueued on the CURRENT stream without any
         synchronisation.  Returns a handle for `recognize_finish`.  `spans`/`batch_size` (the same values `recognize_finish`
         will get) tell the beam kernel which rows share a reference chunk, so it can stop a chunk where the reference's
@@ -167,11 +175,14 @@ class TRBA:
         if mode not in ("greedy", "beam"):
             raise ValueError(f"Unknown mode: {mode}")
         N = canvases_dev.shape[0]
-        bounds, metas = self._device_batches(N, spans, batch_size) if mode == "beam" and spans is not None else \
-            ([(s, min(s + self.device_batch, N)) for s in range(0, N, self.device_batch)], None)
-        meta_dev = None
-        if metas is not None:  # ONE small upload, before any encoder work is queued on this stream
-            meta_dev = torch.from_numpy(np.concatenate(metas)).to(self.device)
+        if mode == "beam" and prepared is not None:
+            bounds, metas, meta_dev = prepared
+            if meta_dev is not None:
+                meta_dev.record_stream(torch.cuda.current_stream())
+        elif mode == "beam" and spans is not None:
+            bounds, metas, meta_dev = self.prepare_chunks(N, spans, batch_size)  # before any encoder work is queued here
+        else:
+            bounds, metas, meta_dev = [(s, min(s + self.device_batch, N)) for s in range(0, N, self.device_batch)], None, None
         parts, off = [], 0
         for k, (lo, hi) in enumerate(bounds):
             cv = canvases_dev[lo:hi]

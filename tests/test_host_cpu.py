@@ -268,3 +268,32 @@ def test_oracle_is_only_a_checker():
                 inside.add(fn.name)
         assert inside <= allowed and len(oracle_imports(tree)) == sum(len(oracle_imports(fn)) for fn in ast.walk(tree)
                                                                       if isinstance(fn, ast.FunctionDef) and fn.name in allowed), (fname, inside)
+
+
+def test_reading_order_host_helper_equals_python_glue(golden_dir):
+    """msocr_reading_order_host (C++ host helper) == sort_boxes_reading_order_with_resolutions + first-equal-word re-match in
+    Python, on the reference-generated fixture boxes and on random layouts with overlaps, zero-size and duplicate boxes."""
+    import json
+
+    from manuscript_ocr_amd._pipeline import _reading_order
+    from manuscript_ocr_amd.detectors import sort_boxes_reading_order_with_resolutions
+
+    def python_order(aabbs):
+        first = {}
+        for k, bx in enumerate(aabbs):
+            first.setdefault(tuple(int(v) for v in bx), k)
+        return [first[tuple(int(v) for v in bx)] for bx in sort_boxes_reading_order_with_resolutions(aabbs)]
+
+    cases = [c["boxes"] for c in json.load(open(os.path.join(golden_dir, "pipeline_glue.json"))) if c["boxes"]]
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 30, 200):
+        for rep in range(4):
+            x0, y0 = rng.integers(0, 900, size=n), rng.integers(0, 600, size=n)
+            w, h = rng.integers(0, 120 if rep < 2 else 30, size=n), rng.integers(0, 40 if rep < 2 else 12, size=n)
+            b = np.stack([x0, y0, x0 + w, y0 + h], 1)
+            if n > 3 and rep % 2:
+                b[n // 2], b[n - 1] = b[0], b[1]
+            cases.append(b.tolist())
+    for c in cases:
+        as_np = [tuple(np.int32(v) for v in bx) for bx in c]  # what the pipeline passes (np.array(polygon, int32))
+        assert _reading_order(np.array(c, dtype=np.int32)) == python_order(as_np), c[:5]
