@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 TRBA_CFG = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+STEP_TIMES = [] if os.environ.get("MSOCR_STEP_TIMES") else None  # diagnostics: host time after every collected step
 TIE_TOL = 5e-3  # first-step logit gap (|logit| ~ 5) treated as a tie between two f32 implementations (tests/conftest.py)
 
 
@@ -62,10 +63,21 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
+    # Native libraries (RCCL prints a version banner) write to the process's stdout; the contract is ONE JSON line there.
+    # Keep the real stdout for that line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or os.environ.get("MSOCR_FORCE_DIST"):  # MSOCR_FORCE_DIST: exercise the RCCL path with a single rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # every lazily created piece of the communicator (first barrier, first all_reduce) before anything is timed
+        warm = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            dist.barrier()
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
 
     from manuscript_ocr_amd import Pipeline, ops, synth
     from manuscript_ocr_amd.detectors import EAST
@@ -120,12 +132,20 @@ def main():
             h_next = pipe.advance_batch(submit()) if i + 1 < k else None
             out_ = pipe.collect_batch(h)
             h = h_next
+            if STEP_TIMES is not None:
+                STEP_TIMES.append(time.perf_counter())
         return out_
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    # Setup, untimed and independent of --warmup: two priming steps (both alternating stream sets, allocator pools, lazily
+    # loaded code objects) followed by the same synchronize + barrier sequence that brackets the timed region, so that
+    # whatever the runtime or RCCL initialise on first use is initialised before the W warm-up steps even when W = 0.
+    run_steps(2)
+    torch.cuda.synchronize()
+    barrier()
     out = None
     out = run_steps(a.warmup) if a.warmup else None
     torch.cuda.synchronize()
@@ -255,8 +275,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out)
 
+    if STEP_TIMES:
+        print("step end times (s):", [round(t - STEP_TIMES[0], 3) for t in STEP_TIMES], file=sys.stderr)
     if rank == 0:
-        print(json.dumps(res))
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
