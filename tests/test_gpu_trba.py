@@ -226,3 +226,28 @@ def test_small_device_batches_give_the_same_results(env):
         assert [r["text"] for r in a] == [r["text"] for r in b]
         np.testing.assert_allclose([r["confidence"] for r in a], [r["confidence"] for r in b], rtol=0, atol=1e-6)
     assert many._device_batches(120, [(0, 120)], 32)[0] == [(0, 32), (32, 64), (64, 96), (96, 120)]
+
+
+def test_random_span_layouts_match_the_full_length_decode(env, monkeypatch):
+    """Randomised page layouts (spans of 1..90 crops, so chunks of 1..32 rows, ragged workgroups, launches of <= 64 rows):
+    ids, run lengths and confidences with the chunk-level early exit == the VALU kernel running all steps."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.recognizers import TRBA
+    sd = synth.trba_state_dict_confident(194, 256, seed=13)
+    rec = TRBA(state_dict=sd, config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda", device_batch=64)
+    rng = np.random.default_rng(99)
+    for trial in range(4):
+        counts = [int(c) for c in rng.choice([1, 2, 3, 5, 31, 32, 33, 64, 90], size=int(rng.integers(1, 5)))]
+        N = sum(counts)
+        spans, o = [], 0
+        for c in counts:
+            spans.append((o, c))
+            o += c
+        canv = torch.from_numpy(synth.synth_crops(1000 + trial, N, 32, 100)).cuda()
+        ids_a, trun_a, conf_a = rec.recognize_canvases(canv, spans=spans)
+        monkeypatch.setenv("MSOCR_BEAM_MFMA", "0")
+        ids_b, trun_b, conf_b = rec.recognize_canvases(canv, spans=spans)
+        monkeypatch.delenv("MSOCR_BEAM_MFMA")
+        assert np.array_equal(trun_a, trun_b), (counts, trun_a, trun_b)
+        assert np.array_equal(ids_a, ids_b), counts
+        np.testing.assert_allclose(conf_a, conf_b, rtol=0, atol=1e-5)
