@@ -193,6 +193,10 @@ def main():
             "words_per_page": len(words) / NP,
             "crops_per_page": n_crops / NP,
             "weights": "seeded synthetic (no checkpoint offline)",
+            "trba_decode": (None if rec is None or not getattr(rec, "last_rows", 0) else
+                            {"max_len": TRBA_CFG["max_len"], "mean_chunk_run_length": round(rec.last_run_length_sum / rec.last_rows, 2),
+                             "note": "the beam kernel leaves the step loop at each 32-crop chunk's run length, like the reference "
+                                     "(model.py:215); 1.8 ms per 960 crops here, 4.2 ms when all 25 steps run"}),
             "parallelism": f"pages sharded over {world} rank(s), no data-path collective; final all_gather of {len(records)} records",
         },
     }
@@ -295,7 +299,7 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=25.0):
+def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=12.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload; also the
     CER of the GPU text against this CPU text on the sampled pages."""
     from oracle import east_model as oem

@@ -226,6 +226,7 @@ class TRBA:
                 for c0 in range(s0, s0 + cnt, batch_size):
                     c1 = min(c0 + batch_size, s0 + cnt)
                     trun[c0:c1] = fin_h[c0:c1].max()
+        self.last_run_length_sum, self.last_rows = getattr(self, "last_run_length_sum", 0) + int(trun.sum()), getattr(self, "last_rows", 0) + N
         trun_dev = torch.from_numpy(trun).to(self.device)
         ids_out, conf_out, logit_out = [], [], []
         for k, (s, hi) in enumerate(handle["bounds"]):
