@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-overlap-steps", action="store_true", help="do not enqueue step i+1's detector work before collecting step i")
     ap.add_argument("--sub-batches", type=int, default=0, help="sub-batch groups pipelined on separate streams (0 = auto)")
     ap.add_argument("--graphs", action="store_true",
-                    help="replay the detector's launch sequence from a hipGraph (measured SLOWER here: 29 vs 42 pages/s, DESIGN.md 7)")
+                    help="replay the detector's launch sequence from a hipGraph (measured 2 % slower than plain launches, DESIGN.md 7)")
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the sub-batch pipeline on ONE stream (no cross-stream kernel overlap): per-kernel profiling mode")
     return ap.parse_args()
