@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--pages", type=int, default=0, help="pages per step per GPU (default 16 pipeline / 8 east)")
     ap.add_argument("--height", type=int, default=1536)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--target-size", type=int, default=0,
+                    help="reference-faithful detector geometry: resize every page to T x T on the device (EAST.predict default T=1280, "
+                         "infer.py:304) instead of feeding the page at its native size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap-steps", action="store_true", help="do not enqueue step i+1's detector work before collecting step i")
@@ -87,10 +90,11 @@ def main():
     from manuscript_ocr_amd.recognizers._trba.net import trba_cnn_macs
 
     H, W = a.height, a.width
+    TW, TH = (a.target_size, a.target_size) if a.target_size else (W, H)  # network input (width, height)
     NP = a.pages or (16 if a.workload == "pipeline" else 8)
     esd = synth.east_state_dict(seed=20260128)
     tsd = synth.trba_state_dict_confident(194, 256, seed=20260128)
-    det = EAST(state_dict=esd, target_size=(W, H), device="cuda", precision=a.precision, use_graphs=a.graphs)
+    det = EAST(state_dict=esd, target_size=(TW, TH), device="cuda", precision=a.precision, use_graphs=a.graphs)
     rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
     if rec is not None and os.environ.get("MSOCR_DEVICE_BATCH"):
@@ -105,7 +109,7 @@ def main():
     for i in range(NP):
         seed = 200 + rank * NP + i
         pg, rects = synth.synth_page(seed, H, W)
-        s, g = synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed)
+        s, g = synth.synth_maps(rects, (H, W), (TH // 4, TW // 4), seed)
         pages.append(pg), scores.append(s), geos.append(g)
     pages_dev = torch.from_numpy(np.stack(pages)).cuda()
     maps_dev = (torch.from_numpy(np.stack(scores)).cuda(), torch.from_numpy(np.stack(geos)).cuda())
@@ -165,7 +169,7 @@ def main():
     total_pages = NP * a.steps * world
     words = [w for p in out for b in p.blocks for w in b.words]
     n_crops = sum(1 for w in words if w.text is not None)
-    gflop_page = 2 * east_conv_macs(H, W) / 1e9
+    gflop_page = 2 * east_conv_macs(TH, TW) / 1e9
     res = {
         "metric": "manuscript pages/sec end-to-end (EAST+TRBA) at 1/2/4/8 MI355X; CER vs CPU ref",
         "value": total_pages / dt,
@@ -180,11 +184,12 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16"}[a.precision],
         "data": "synthetic",
         "config": {
-            "workload": (f"full EAST->crop->TRBA pipeline (BASELINE configs[3]): batch={NP} pages @ {W}x{H} per GPU, native network "
-                         f"input {H}x{W}; EAST forward + decode + LANMS + filters + reading order + device crop/ResizeAndPadA + "
+            "workload": (f"full EAST->crop->TRBA pipeline (BASELINE configs[3]): batch={NP} pages @ {W}x{H} per GPU, "
+                         + (f"native network input {H}x{W}" if not a.target_size else f"pages resized to {TW}x{TH} on the device") +
+                         f"; EAST forward + decode + LANMS + filters + reading order + device crop/ResizeAndPadA + "
                          "TRBA 32x100 beam-8; decode/NMS on injected synthetic maps (random weights give unusable maps)")
             if a.workload == "pipeline" else
-            (f"EAST detector only (BASELINE configs[1]): batch={NP} pages @ {W}x{H} per GPU, native network input {H}x{W}; "
+            (f"EAST detector only (BASELINE configs[1]): batch={NP} pages @ {W}x{H} per GPU, network input {TH}x{TW}; "
              "forward + decode + LANMS + filters; decode/NMS on injected synthetic maps"),
             "pages_per_step_per_gpu": NP,
             "page_hw": [H, W],
@@ -277,7 +282,7 @@ def main():
                     fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} {tag[3]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out)
+        res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out, target_wh=(TW, TH))
 
     if STEP_TIMES:
         print("step end times (s):", [round(t - STEP_TIMES[0], 3) for t in STEP_TIMES], file=sys.stderr)
@@ -299,7 +304,7 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=12.0):
+def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=12.0, target_wh=None):
     """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload; also the
     CER of the GPU text against this CPU text on the sampled pages."""
     from oracle import east_model as oem
@@ -309,6 +314,7 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     from oracle import pipeline_glue as G
     from oracle import trba_model as otm
 
+    TW, TH = target_wh if target_wh else (W, H)
     net = oem.EASTNet()
     net.load_state_dict(esd)
     net.eval()
@@ -321,8 +327,8 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     edits = chars = mism = n_words = n_diff = n_tie = 0
     with torch.no_grad():
         for pi, (pg, s, g) in enumerate(zip(pages, scores, geos)):
-            net(torch.from_numpy(imgproc.east_preprocess(pg, W, H)))
-            quads = P.east_postprocess(s, g, (H, W), (W, H), L.locality_aware_nms)
+            net(torch.from_numpy(imgproc.east_preprocess(pg, TW, TH)))
+            quads = P.east_postprocess(s, g, (H, W), (TW, TH), L.locality_aware_nms)
             if workload == "pipeline":
                 polys = [q[:8].reshape(4, 2).tolist() for q in quads]
                 order, kept, crops = G.order_and_crop(polys, pg, 5)
