@@ -43,7 +43,7 @@ def test_crop_resize_pad_bit_exact_vs_oracle(gpu):
             assert np.array_equal(got[k], exp), (k, boxes[k], ih, iw, np.abs(got[k].astype(int) - exp.astype(int)).max())
 
 
-def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5):
+def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5, target_wh=None):
     """The reference path on the CPU: infer.py:319-363 + _pipeline.py:100-162 + TRBA.predict (beam defaults)."""
     from oracle import east_post as P
     from oracle import imgproc
@@ -51,7 +51,7 @@ def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5):
     from oracle import pipeline_glue as G
     from oracle import trba_model as otm
     H, W = page.shape[:2]
-    quads = P.east_postprocess(score, geo, (H, W), (W, H), L.locality_aware_nms)
+    quads = P.east_postprocess(score, geo, (H, W), target_wh or (W, H), L.locality_aware_nms)
     polys = [q[:8].reshape(4, 2).tolist() for q in quads]
     order, kept, crops = G.order_and_crop(polys, page, min_text_size)
     res = []
@@ -222,3 +222,35 @@ def test_square_target_size_resize_and_scale_back(gpu):
     exp = P.east_postprocess(score, geo, (300, 420), T, L.locality_aware_nms)
     got = np.array([[c for pt in w.polygon for c in pt] + [w.detection_confidence] for w in res["page"].blocks[0].words], dtype=np.float32)
     assert len(exp) >= 3 and got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_config0_default_geometry_1280x720_page(gpu):
+    """BASELINE configs[0]: one 1280x720 page through Pipeline with the reference's default detector geometry (the page is
+    resized to 1280x1280 ignoring the aspect ratio, boxes scaled back by (w/T, h/T), infer.py:304,134-147), injected maps at
+    320x320; Pipeline.predict (device path) == the CPU path: boxes, order, texts, confidences."""
+    from conftest import compare_texts
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import trba_model as otm
+    H, W, T = 720, 1280, 1280
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    tsd = synth.trba_state_dict_confident(194, 256, seed=20260128)
+    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), device="cuda"), TRBA(state_dict=tsd, config=cfg, device="cuda"))
+    assert pipe.detector.target_size == T
+    page, rects = synth.synth_page(1, H, W)
+    score, geo = synth.synth_maps(rects, (H, W), (T // 4, T // 4), 1)
+    mo = (torch.from_numpy(score)[None].cuda(), torch.from_numpy(geo)[None].cuda())
+    got = pipe.predict_batch([page], _maps_override=mo)[0]
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(tsd)
+    ref_net.eval()
+    itos, _ = otm.load_charset(CHARSET)
+    exp = _oracle_pipeline(page, score, geo, ref_net, itos, cfg, target_wh=(T, T))
+    gw = got.blocks[0].words
+    assert len(gw) == len(exp) and len(exp) >= 40
+    assert [[tuple(p) for p in a.polygon] for a in gw] == [[tuple(p) for p in b["polygon"]] for b in exp]
+    with_text = [(a, b) for a, b in zip(gw, exp) if b["rec"] is not None]
+    same = compare_texts([a.text for a, _ in with_text], [b for _, b in with_text], itos)
+    assert len(same) >= len(with_text) - 1
+    np.testing.assert_allclose([with_text[i][0].recognition_confidence for i in same], [with_text[i][1]["rec"] for i in same], atol=1e-4)
