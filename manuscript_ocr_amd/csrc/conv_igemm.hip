@@ -82,7 +82,10 @@ __device__ __forceinline__ int swz(int row) {
   return (row / RPB) & (CPR - 1);
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2>
+// LEAN: 1x1 kernel without padding (every 1x1 convolution and the batched GEMMs of the Winograd path) — a K-tile is a plain
+// pointer increment, no tap decoding, no bounds masks (rows >= M load valid garbage that the epilogue never stores).  PMC on
+// the Winograd GEMM counted 1.9 VALU + 1.2 SALU instructions per MFMA in the general loader; they share the SIMD's issue port.
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false>
 __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
@@ -153,7 +156,19 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
   u32x4 ra[A_IT], rb[B_IT];
   uint32_t a_ok[A_IT];
 
+  const char* a_ptr[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) a_ptr[i] = g_in + a_base[i] * ES;
   auto load_tile = [&](int kt) {
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (long)kt * BKB);
+#pragma unroll
+      for (int j = 0; j < B_IT; ++j) {
+        if (BN % RPP == 0 || row0 + j * RPP < BN) rb[j] = *reinterpret_cast<const u32x4*>(b_ptr[j] + (long)kt * BKB);
+      }
+      return;
+    }
     const int tap = kt / p.cin_tiles;
     const int c0 = (kt - tap * p.cin_tiles) * BK;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
     for (int i = 0; i < A_IT; ++i) {
       const int row = row0 + i * RPP;
       u32x4 v = ra[i];
-      v[0] &= a_ok[i]; v[1] &= a_ok[i]; v[2] &= a_ok[i]; v[3] &= a_ok[i];
+      if constexpr (!LEAN) { v[0] &= a_ok[i]; v[1] &= a_ok[i]; v[2] &= a_ok[i]; v[3] &= a_ok[i]; }
       *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = v;
     }
 #pragma unroll
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -329,7 +344,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI = (BM / WM) * 32 * BN * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES>;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -351,10 +366,19 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
   // prologue/epilogue, worth 3-5 % on the short-K (Winograd, 1x1) launches; variant 0: register-staged double buffer, 2/CU.
   static const int variant = getenv("MSOCR_CONV_VARIANT") ? atoi(getenv("MSOCR_CONV_VARIANT")) : (sizeof(T) == 4 ? 1 : 0);
   if (p.Cout % 128 == 0) {
+    if constexpr (sizeof(T) == 4) {
+      static const int lean_on = getenv("MSOCR_CONV_LEAN") ? atoi(getenv("MSOCR_CONV_LEAN")) : 1;
+      if (wide && variant == 1 && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
+        return launch_cfg<T, 128, 128, 128, 64, 64, 1, true>(p, s);
+    }
     if (wide && variant == 1) return launch_cfg<T, 128, 128, 128, 64, 64, 1>(p, s);
     if (variant == 2 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1>(p, s);
     return wide ? launch_cfg<T, 128, 128, 128, 64, 64>(p, s) : launch_cfg<T, 128, 128, 64, 64, 64>(p, s);
   } else if (p.Cout % 64 == 0) {
+    if constexpr (sizeof(T) == 4) {
+      static const int lean_on = getenv("MSOCR_CONV_LEAN") ? atoi(getenv("MSOCR_CONV_LEAN")) : 1;
+      if (wide && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0) return launch_cfg<T, 128, 64, 128, 64, 32, 2, true>(p, s);
+    }
     return wide ? launch_cfg<T, 128, 64, 128, 64, 32>(p, s) : launch_cfg<T, 128, 64, 64, 64, 32>(p, s);
   } else {
     return wide ? launch_cfg<T, 256, 32, 128, 64, 32>(p, s) : launch_cfg<T, 256, 32, 64, 64, 32>(p, s);
