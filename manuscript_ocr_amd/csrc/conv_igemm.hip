@@ -28,6 +28,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// 16 zero bytes: padded (out-of-image) taps load from here, so the operand tile needs no masking
+__device__ __attribute__((aligned(16))) uint32_t msocr_zero16[4] = {0u, 0u, 0u, 0u};
+
 struct ConvParams {
   const char* in;
   const char* w;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
   }
 
   u32x4 ra[A_IT], rb[B_IT];
-  uint32_t a_ok[A_IT];
+  int t_kh = 0, t_kw = 0, t_c0 = 0;  // tap and channel offset of the NEXT K-tile load_tile() will fetch
 
   const char* a_ptr[A_IT];
 #pragma unroll
@@ -169,22 +172,24 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
       }
       return;
     }
-    const int tap = kt / p.cin_tiles;
-    const int c0 = (kt - tap * p.cin_tiles) * BK;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const long koff = (long)kh * p.sH + (long)kw * p.sW + c0;
+    // (kh, kw, c0) of K-tile kt, advanced incrementally (tiles are visited in order 0, 1, 2, ...): no divisions in the loop
+    const long koff = (long)t_kh * p.sH + (long)t_kw * p.sW + t_c0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+      const int hi = a_hi0[i] + t_kh, wi = a_wi0[i] + t_kw;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      // branch-free: out-of-image taps read the (always valid) first 16 bytes of the tensor and are masked to zero
-      const long off = ok ? (a_base[i] + koff) : 0;
-      ra[i] = *reinterpret_cast<const u32x4*>(g_in + off * ES);
-      a_ok[i] = ok ? 0xffffffffu : 0u;  // applied when the tile is written to LDS: the load itself stays in flight
+      // branch-free: out-of-image taps read 16 zero bytes
+      const char* src = ok ? g_in + (a_base[i] + koff) * ES : reinterpret_cast<const char*>(msocr_zero16);
+      ra[i] = *reinterpret_cast<const u32x4*>(src);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
       if (BN % RPP == 0 || row0 + j * RPP < BN) rb[j] = *reinterpret_cast<const u32x4*>(b_ptr[j] + (long)kt * BKB);
+    }
+    t_c0 += BK;
+    if (t_c0 == p.Cin) {
+      t_c0 = 0;
+      if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
     }
   };
   auto store_tile = [&](int stage) {
@@ -193,9 +198,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = row0 + i * RPP;
-      u32x4 v = ra[i];
-      if constexpr (!LEAN) { v[0] &= a_ok[i]; v[1] &= a_ok[i]; v[2] &= a_ok[i]; v[3] &= a_ok[i]; }
-      *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = v;
+      *reinterpret_cast<u32x4*>(sa + row * BKB + ((chunk ^ swz<BKB>(row)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
