@@ -7,7 +7,7 @@ Copies the two kernel_stats.csv files and writes profiles/<tag>_pmc_traffic.json
 stage (conv_igemm_kernel instances + the two Winograd transform kernels), FETCH_SIZE doubled as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (wide coalesced reads are counted at 64 B per 128-B
 request), WRITE_SIZE as reported; both counters in KiB, collected in separate --pmc passes of
-`bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1` (2 steps executed -> divided by 2)."""
+`bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1` (2 priming + 1 warm-up + 1 timed step -> divided by 4)."""
 import collections
 import csv
 import glob
@@ -47,7 +47,7 @@ def main():
     shutil.copy(one(os.path.join(conc, "runc", "*_kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats_concurrent.csv"))
     shutil.copy(one(os.path.join(ser, "runc", "*_kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats_serialized.csv"))
     fe, wr = pmc(fetch, "FETCH_SIZE"), pmc(write, "WRITE_SIZE")
-    steps = 2.0
+    steps = 4.0  # bench.py executes 2 priming + 1 warm-up + 1 timed step with --steps 1 --warmup 1
     per = {}
     tot = 0.0
     for n in sorted(set(fe) | set(wr)):
