@@ -122,10 +122,42 @@ def main():
             return pipe.collect_batch(submit())
         return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
 
+    # detector-only workload (BASELINE configs[1]): groups of 2 pages on their own streams, two stream sets, the groups of step
+    # i+1 enqueued before step i's boxes are read back and filtered on the host
+    east_bounds = [(lo, min(lo + 2, NP)) for lo in range(0, NP, 2)]
+    east_streams = [[torch.cuda.Stream() for _ in east_bounds] for _ in range(2)] if pipe is None else None
+
+    def east_submit(i):
+        main = torch.cuda.current_stream()
+        hs = []
+        for st, (lo, hi) in zip(east_streams[i & 1], east_bounds):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                hs.append((st, lo, hi, det.detect_start(pages_dev[lo:hi], (maps_dev[0][lo:hi], maps_dev[1][lo:hi]))))
+        return hs
+
+    def east_collect(hs):
+        main, res = torch.cuda.current_stream(), []
+        for st, lo, hi, h in hs:
+            with torch.cuda.stream(st):
+                res += [r["page"] for r in det.detect_finish(h, pages[lo:hi])]
+            main.wait_stream(st)
+        return res
+
+    def run_steps_east(k):
+        h, out_ = east_submit(0), None
+        for i in range(k):
+            h_next = east_submit(i + 1) if i + 1 < k else None
+            out_ = east_collect(h)
+            h = h_next
+        return out_
+
     def run_steps(k):
         """k steps, software-pipelined across steps: the detector work of step i+1 is enqueued and its host stage
         (box filters, reading order, crop descriptors -> recogniser enqueue) runs BEFORE step i is collected, so the
         device always holds queued recogniser work while the host annotates step i.  All work of the k steps is inside."""
+        if pipe is None and not (a.serialize_streams or a.no_overlap_steps):
+            return run_steps_east(k)
         if pipe is None or a.serialize_streams or a.no_overlap_steps:
             out_ = None
             for _ in range(k):
