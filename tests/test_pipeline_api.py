@@ -108,3 +108,32 @@ def test_reading_order_and_process_batch():
     pages = p.process_batch([IMG, IMG])
     assert len(pages) == 2 and all(isinstance(x, Page) for x in pages)
     assert p.min_text_size == 5 and p.detector is not None and p.recognizer is not None
+
+
+def test_public_signatures_match_the_reference_kwargs():
+    """Drop-in contract: constructor / predict keyword names, order and defaults of the reference's public API
+    (detectors/_east/infer.py:28-43,235-241; recognizers/_trba/__init__.py:37-44,290-299; _pipeline.py:18-24,56-62), followed
+    only by this package's keyword-only extras."""
+    import inspect
+
+    from manuscript_ocr_amd import Pipeline
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+
+    def params(fn):
+        return [(n, p.default) for n, p in inspect.signature(fn).parameters.items()
+                if n != "self" and p.kind in (p.POSITIONAL_OR_KEYWORD,)]
+
+    assert params(EAST.__init__) == [
+        ("weights_path", None), ("device", None), ("target_size", 1280), ("expand_ratio_w", 0.9), ("expand_ratio_h", 0.9),
+        ("score_thresh", 0.6), ("iou_threshold", 0.2), ("score_geo_scale", 0.25), ("quantization", 2),
+        ("axis_aligned_output", True), ("remove_area_anomalies", True), ("anomaly_sigma_threshold", 5.0),
+        ("anomaly_min_box_count", 30)]
+    assert params(EAST.predict) == [("img_or_path", inspect.Parameter.empty), ("vis", False), ("profile", False),
+                                    ("return_maps", False), ("sort_reading_order", False)]
+    assert params(TRBA.__init__) == [("model_path", None), ("charset_path", None), ("config_path", None), ("device", "auto")]
+    assert params(TRBA.predict) == [("images", inspect.Parameter.empty), ("batch_size", 32), ("mode", "beam"), ("beam_size", 8),
+                                    ("temperature", 1.7), ("alpha", 0.9)]
+    assert params(Pipeline.__init__) == [("detector", None), ("recognizer", None), ("min_text_size", 5)]
+    assert params(Pipeline.predict) == [("image", inspect.Parameter.empty), ("recognize_text", True), ("vis", False), ("profile", False)]
+    assert [n for n, _ in params(Pipeline.get_text)] == ["page"]
