@@ -163,11 +163,14 @@ def main():
             for _ in range(k):
                 out_ = step()
             return out_
-        h, out_ = pipe.advance_batch(submit()), None
+        depth = int(os.environ.get("MSOCR_PIPE_DEPTH", "1"))  # batches advanced ahead of the one being collected
+        pipe.stream_sets = depth + 1
+        queue, out_, nsub = [], None, 0
         for i in range(k):
-            h_next = pipe.advance_batch(submit()) if i + 1 < k else None
-            out_ = pipe.collect_batch(h)
-            h = h_next
+            while nsub < k and len(queue) <= depth:
+                queue.append(pipe.advance_batch(submit()))
+                nsub += 1
+            out_ = pipe.collect_batch(queue.pop(0))
             if STEP_TIMES is not None:
                 STEP_TIMES.append(time.perf_counter())
         return out_

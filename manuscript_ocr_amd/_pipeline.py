@@ -212,9 +212,10 @@ class Pipeline:
             # before it can enqueue the long recogniser tail: with equal priorities the detector kernels of batch i+1 share the
             # chip fairly with the recogniser of batch i and finish together with it, so the next recogniser work is enqueued
             # only when the device has already drained (measured: 5 % idle); at high priority they overtake it.
-            if not hasattr(self, "_stream_sets"):
-                self._stream_sets, self._det_stream_sets, self._set_idx = [[], []], [[], []], 0
-            self._set_idx ^= 1
+            nsets = max(2, int(getattr(self, "stream_sets", 2)))  # batches that may be in flight at once
+            if not hasattr(self, "_stream_sets") or len(self._stream_sets) != nsets:
+                self._stream_sets, self._det_stream_sets, self._set_idx = [[] for _ in range(nsets)], [[] for _ in range(nsets)], 0
+            self._set_idx = (self._set_idx + 1) % nsets
             pool, dpool = self._stream_sets[self._set_idx], self._det_stream_sets[self._set_idx]
             hi_prio = -1 if getattr(self, "det_stream_priority", True) else 0
             while len(pool) < nsub:
