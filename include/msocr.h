@@ -105,6 +105,23 @@ int64_t msocr_lanms_workspace_bytes(int N, int max_cand);
 int msocr_east_lanms(const float* cand, const int32_t* counts, int N, int max_cand, double iou_thr, float* boxes_out,
                      int32_t* nbox_out, void* workspace, void* stream);
 
+/* The box filters of EAST.predict after the NMS (infer.py:340-356): expand_boxes (utils.py:384-422), scale to the original
+ * page (infer.py:134-147), removal of fully contained boxes (infer.py:174-214, cv2.pointPolygonTest restated), area anomalies
+ * (infer.py:216-233, np.mean / np.std with NumPy's f32 pairwise summation) and axis-aligned conversion (infer.py:149-172), with
+ * NumPy's f32 operation order: bit-identical to the host implementation.  expand_w/h, scale_x = orig_w / target_w,
+ * scale_y = orig_h / target_h and sigma are the Python floats of the reference (rounded to f32 where NumPy does).
+ * msocr_east_box_tail: one workgroup per page on boxes [N][max_cand][9] / nbox [N] from msocr_east_lanms ->
+ * out [N][max_cand][9], n_out [N] (-1 for a page with more than 2048 boxes: use the host path); workspace:
+ * msocr_east_box_tail_workspace_bytes(N) bytes.
+ * msocr_east_box_tail_host: HOST twin running the same code on the CPU (quads_host [M][9] -> out_host [<=M][9], *n_out_host). */
+int64_t msocr_east_box_tail_workspace_bytes(int N);
+int msocr_east_box_tail(const float* boxes, const int32_t* nbox, int N, int max_cand, double expand_w, double expand_h,
+                        double scale_x, double scale_y, int axis_aligned_output, int remove_anomalies, double sigma, int min_count,
+                        float* out, int32_t* n_out, void* workspace, void* stream);
+int msocr_east_box_tail_host(const float* quads_host, int M, double expand_w, double expand_h, double scale_x, double scale_y,
+                             int axis_aligned_output, int remove_anomalies, double sigma, int min_count, float* out_host,
+                             int32_t* n_out_host);
+
 /* ---- TRBA ---------------------------------------------------------------------------------------------- */
 
 /* SELayer (recognizers/_trba/model/seresnet31.py:5-20) fused with the residual tail of SEBasicBlock.forward

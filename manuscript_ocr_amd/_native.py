@@ -58,6 +58,9 @@ _SIGS = {
     "msocr_attn_beam_finalize": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "msocr_seq_confidence": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_crop_resize_pad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_east_box_tail_workspace_bytes": (c_i64, [c_i32]),
+    "msocr_east_box_tail": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_i32, c_f64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_east_box_tail_host": (c_i32, [c_vp, c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_i32, c_f64, c_i32, c_vp, c_vp]),
     "msocr_reading_order_host": (c_i32, [c_vp, c_i32, c_f64, c_f64, c_vp]),
     "msocr_nchw_f32_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "msocr_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),

@@ -103,6 +103,7 @@ class EAST:
         """pages_dev [N,h,w,3] u8 on the device (any size) -> device tensors
         (score, geo, boxes [N,max_cand,9], nbox [N]).  Resize, network, decode and LANMS, all HIP."""
         tw, th = self._target_wh()
+        oh, ow = int(pages_dev.shape[1]), int(pages_dev.shape[2])
         if pages_dev.shape[1] != th or pages_dev.shape[2] != tw:
             pages_dev = ops.resize_linear_u8(pages_dev, th, tw)
         score, geo = self.model.forward(pages_dev)
@@ -112,7 +113,13 @@ class EAST:
         cand, counts = ops.east_decode(score, geo, self.score_thresh, 1.0 / self.score_geo_scale, self.quantization,
                                        self.max_candidates)
         boxes, nbox = ops.east_lanms(cand, counts, self.iou_threshold)
-        return score, geo, boxes, nbox, counts
+        fboxes = fn = None
+        if getattr(self, "device_tail", True):
+            # infer.py:340-356 on the device: expand, scale back to the page, contained boxes, area anomalies, axis-aligned
+            fboxes, fn = ops.east_box_tail(boxes, nbox, self.expand_ratio_w, self.expand_ratio_h, ow / tw, oh / th,
+                                           self.axis_aligned_output, self.remove_area_anomalies, self.anomaly_sigma_threshold,
+                                           self.anomaly_min_box_count)
+        return score, geo, boxes, nbox, counts, fboxes, fn
 
     def _host_tail(self, quads: np.ndarray, orig_hw) -> np.ndarray:
         """infer.py:340-356 on the (M,9) f32 NMS output."""
@@ -176,22 +183,27 @@ class EAST:
 
     def detect_finish(self, handle, imgs, vis=False, profile=False, return_maps=False, sort_reading_order=False):
         """Wait for `handle` (from detect_start), then the host tail (infer.py:340-390) -> list of result dicts."""
-        inst = handle[5]
+        inst = handle[7]
         try:
             t0 = time.time()
-            score, geo, boxes, nbox, counts, _ = handle
+            score, geo, boxes, nbox, counts, fboxes, fn, _ = handle
             nbox_h = nbox.cpu().numpy()
             counts_h = counts.cpu().numpy()
             if np.any(counts_h < 0):
                 raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
-            boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
+            fn_h = fn.cpu().numpy() if fn is not None else None
+            on_device = fn_h is not None and bool(np.all(fn_h >= 0))  # a page with > 2048 boxes leaves the tail to the host
+            if on_device:
+                final_h = fboxes[:, : max(int(fn_h.max()), 1)].cpu().numpy()
+            else:
+                boxes_h = boxes[:, : max(int(nbox_h.max()), 1)].cpu().numpy()
             if profile:
                 print(f"  Model inference + decode + NMS (device wait): {time.time() - t0:.3f}s")
                 print(f"    Boxes after NMS: {[int(v) for v in nbox_h]}")
             t_dev = time.time() - t0
             results = []
             for n, img in enumerate(imgs):
-                quads = self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
+                quads = final_h[n, : fn_h[n]] if on_device else self._host_tail(boxes_h[n, : nbox_h[n]], img.shape[:2])
                 words = self._words(quads)
                 if sort_reading_order and words:
                     words = self._sort_words(words)

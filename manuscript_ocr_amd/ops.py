@@ -199,6 +199,21 @@ def east_lanms(cand, counts, iou_thr, workspace=None):
     return boxes, nbox
 
 
+def east_box_tail(boxes, nbox, expand_w, expand_h, scale_x, scale_y, axis_aligned, remove_anomalies, sigma, min_count):
+    """boxes [N,max_cand,9] f32 + nbox [N] i32 (device, from east_lanms) -> (final boxes [N,max_cand,9], counts [N] i32; -1 = page
+    with more than 2048 boxes, to be finished by the host path).  expand / scale / contained / anomalies / axis-aligned."""
+    _need_cuda(boxes, nbox)
+    N, max_cand, _ = boxes.shape
+    ws = torch.empty((nat.lib().msocr_east_box_tail_workspace_bytes(N),), dtype=torch.uint8, device=boxes.device)
+    out = torch.empty_like(boxes)
+    n_out = torch.empty((N,), dtype=torch.int32, device=boxes.device)
+    nat.check(nat.lib().msocr_east_box_tail(boxes.data_ptr(), nbox.data_ptr(), N, max_cand, float(expand_w), float(expand_h),
+                                            float(scale_x), float(scale_y), int(bool(axis_aligned)), int(bool(remove_anomalies)),
+                                            float(sigma), int(min_count), out.data_ptr(), n_out.data_ptr(), ws.data_ptr(), _stream()),
+              "east_box_tail")
+    return out, n_out
+
+
 def nchw_to_nhwc(x_f32, dtype, out=None):
     _need_cuda(x_f32)
     N, C, H, W = x_f32.shape

@@ -353,3 +353,57 @@ def test_lanms_many_unmerged_polygons_general_nms_path(ops):
     nb = int(nbox.cpu()[0])
     assert nb == len(exp)
     assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+def _random_quads(rng, M, trial):
+    cx, cy = rng.random(M) * 1800, rng.random(M) * 1400
+    w, h = rng.random(M) * 150 + 2, rng.random(M) * 40 + 2
+    if trial % 3 == 0 and M > 4:  # nested boxes and a giant one
+        cx[1], cy[1], w[1], h[1] = cx[0], cy[0], w[0] * 0.5, h[0] * 0.5
+        w[2], h[2] = 1500, 900
+    ang = (rng.random(M) - 0.5) * 0.4
+    pts = np.stack([np.stack([-w / 2, -h / 2], 1), np.stack([w / 2, -h / 2], 1), np.stack([w / 2, h / 2], 1), np.stack([-w / 2, h / 2], 1)], 1)
+    if trial % 5 == 0:
+        pts = pts[:, ::-1]
+    c, s_ = np.cos(ang), np.sin(ang)
+    R = np.stack([np.stack([c, -s_], 1), np.stack([s_, c], 1)], 1)
+    pts = np.einsum("mij,mkj->mki", R, pts) + np.stack([cx, cy], 1)[:, None, :]
+    q = np.concatenate([pts.reshape(M, 8), rng.random((M, 1))], 1).astype(np.float32)
+    if trial % 7 == 0:
+        q[:, :8] = np.round(q[:, :8])
+    return q
+
+
+def test_east_box_tail_device_equals_numpy_host_tail(ops):
+    """msocr_east_box_tail (expand, scale, contained-box removal, area anomalies, axis-aligned; one workgroup per page) against the
+    NumPy host tail of detectors/_east/post.py: bit-identical boxes, page by page, over random layouts with nested / giant /
+    reversed / integer-coordinate quads and all parameter combinations; pages with more than 2048 boxes are flagged (-1)."""
+    from manuscript_ocr_amd.detectors._east import post
+    rng = np.random.default_rng(5)
+    for trial in range(24):
+        counts = [int(c) for c in rng.choice([0, 1, 2, 5, 31, 32, 60, 200, 500, 1500], size=3)]
+        max_cand = 2304
+        kw = dict(ew=float(rng.choice([0.9, 0.0, 0.3])), eh=float(rng.choice([0.9, 0.0, 0.5])), aa=bool(trial % 2), anom=bool(trial % 4),
+                  minc=int(rng.choice([30, 5])))
+        ohw = (int(rng.choice([1536, 720, 4250])), int(rng.choice([2048, 1280, 5390])))
+        twh = (int(rng.choice([1280, 2048])), int(rng.choice([1280, 1536])))
+        boxes = np.zeros((3, max_cand, 9), dtype=np.float32)
+        quads = []
+        for pg, M in enumerate(counts):
+            q = _random_quads(rng, M, trial + pg)
+            boxes[pg, :M] = q
+            quads.append(q)
+        out, n_out = ops.east_box_tail(torch.from_numpy(boxes).cuda(), torch.tensor(counts, dtype=torch.int32).cuda(), kw["ew"], kw["eh"],
+                                       ohw[1] / twh[0], ohw[0] / twh[1], kw["aa"], kw["anom"], 5.0, kw["minc"])
+        out, n_out = out.cpu().numpy(), n_out.cpu().numpy()
+        for pg, q in enumerate(quads):
+            e = post.expand_boxes(q.copy(), kw["ew"], kw["eh"])
+            e = post.scale_boxes(e, ohw, twh)
+            e = post.remove_contained(e)
+            e = post.remove_area_anomalies(e, kw["anom"], 5.0, kw["minc"])
+            e = post.to_axis_aligned(e) if kw["aa"] else e
+            assert n_out[pg] == len(e), (trial, pg, counts[pg], n_out[pg], len(e))
+            assert np.array_equal(out[pg, : len(e)], e), (trial, pg)
+    big = torch.zeros((1, 2304, 9), dtype=torch.float32).cuda()
+    _, n_big = ops.east_box_tail(big, torch.tensor([2100], dtype=torch.int32).cuda(), 0.9, 0.9, 1.0, 1.0, True, True, 5.0, 30)
+    assert int(n_big[0]) == -1

@@ -254,3 +254,28 @@ def test_config0_default_geometry_1280x720_page(gpu):
     same = compare_texts([a.text for a, _ in with_text], [b for _, b in with_text], itos)
     assert len(same) >= len(with_text) - 1
     np.testing.assert_allclose([with_text[i][0].recognition_confidence for i in same], [with_text[i][1]["rec"] for i in same], atol=1e-4)
+
+
+def test_device_box_tail_equals_host_tail_end_to_end(gpu):
+    """EAST with the box filters on the device (default) == the same detector finishing the NMS boxes with the NumPy host tail:
+    identical polygons and confidences on injected-map pages (native and square-resize geometry)."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.detectors import EAST
+    H, W = 512, 768
+    for tsize in ((W, H), 640):
+        det = EAST(state_dict=synth.east_state_dict(), target_size=tsize, device="cuda")
+        tw, th = det._target_wh()
+        pages, maps = [], []
+        for seed in (51, 52, 53):
+            pg, rects = synth.synth_page(seed, H, W)
+            pages.append(pg)
+            maps.append(synth.synth_maps(rects, (H, W), (th // 4, tw // 4), seed))
+        mo = (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())
+        det.device_tail = True
+        a = det.predict_batch(pages, _maps_override=mo)
+        det.device_tail = False
+        b = det.predict_batch(pages, _maps_override=mo)
+        for ra, rb in zip(a, b):
+            wa, wb = ra["page"].blocks[0].words, rb["page"].blocks[0].words
+            assert len(wa) == len(wb) and len(wa) > 20
+            assert [(w.polygon, w.detection_confidence) for w in wa] == [(w.polygon, w.detection_confidence) for w in wb]

@@ -297,3 +297,42 @@ def test_reading_order_host_helper_equals_python_glue(golden_dir):
     for c in cases:
         as_np = [tuple(np.int32(v) for v in bx) for bx in c]  # what the pipeline passes (np.array(polygon, int32))
         assert _reading_order(np.array(c, dtype=np.int32)) == python_order(as_np), c[:5]
+
+
+def test_box_tail_host_twin_equals_numpy_tail():
+    """msocr_east_box_tail_host (the __host__ __device__ arithmetic of the device box filters, run on the CPU) == the NumPy
+    host tail (expand_boxes, scale, contained boxes, area anomalies with NumPy's pairwise f32 sums, axis-aligned): bit-identical
+    on random layouts with nested / giant / reversed / integer-coordinate quads and all parameter combinations."""
+    from manuscript_ocr_amd import _native as nat
+    from manuscript_ocr_amd.detectors._east import post
+    rng = np.random.default_rng(5)
+    for trial in range(120):
+        M = int(rng.choice([0, 1, 2, 5, 20, 31, 32, 60, 200, 400]))
+        cx, cy = rng.random(M) * 1800, rng.random(M) * 1400
+        w, h = rng.random(M) * 150 + 2, rng.random(M) * 40 + 2
+        if trial % 3 == 0 and M > 4:
+            cx[1], cy[1], w[1], h[1] = cx[0], cy[0], w[0] * 0.5, h[0] * 0.5
+            w[2], h[2] = 1500, 900
+        ang = (rng.random(M) - 0.5) * 0.4
+        pts = np.stack([np.stack([-w / 2, -h / 2], 1), np.stack([w / 2, -h / 2], 1), np.stack([w / 2, h / 2], 1), np.stack([-w / 2, h / 2], 1)], 1)
+        if trial % 5 == 0:
+            pts = pts[:, ::-1]
+        c, s_ = np.cos(ang), np.sin(ang)
+        R = np.stack([np.stack([c, -s_], 1), np.stack([s_, c], 1)], 1)
+        pts = np.einsum("mij,mkj->mki", R, pts) + np.stack([cx, cy], 1)[:, None, :]
+        q = np.concatenate([pts.reshape(M, 8), rng.random((M, 1))], 1).astype(np.float32)
+        if trial % 7 == 0:
+            q[:, :8] = np.round(q[:, :8])
+        ew, eh = float(rng.choice([0.9, 0.0, 0.3])), float(rng.choice([0.9, 0.0, 0.5]))
+        aa, anom, minc = bool(trial % 2), bool(trial % 4), int(rng.choice([30, 5]))
+        ohw = (int(rng.choice([1536, 720, 4250])), int(rng.choice([2048, 1280, 5390])))
+        twh = (int(rng.choice([1280, 2048])), int(rng.choice([1280, 1536])))
+        e = post.expand_boxes(q.copy(), ew, eh)
+        e = post.scale_boxes(e, ohw, twh)
+        e = post.remove_contained(e)
+        e = post.remove_area_anomalies(e, anom, 5.0, minc)
+        e = post.to_axis_aligned(e) if aa else e
+        out, n = np.empty((max(M, 1), 9), np.float32), ctypes.c_int32(0)
+        rc = nat.lib().msocr_east_box_tail_host(np.ascontiguousarray(q).ctypes.data, M, ew, eh, ohw[1] / twh[0], ohw[0] / twh[1], int(aa), int(anom),
+                                                5.0, minc, out.ctypes.data, ctypes.byref(n))
+        assert rc == 0 and n.value == len(e) and np.array_equal(out[: n.value], e), (trial, M)
