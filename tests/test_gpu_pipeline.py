@@ -279,3 +279,21 @@ def test_device_box_tail_equals_host_tail_end_to_end(gpu):
             wa, wb = ra["page"].blocks[0].words, rb["page"].blocks[0].words
             assert len(wa) == len(wb) and len(wa) > 20
             assert [(w.polygon, w.detection_confidence) for w in wa] == [(w.polygon, w.detection_confidence) for w in wb]
+        # a page the device tail refuses (more than 2048 boxes -> count -1) sends the whole batch through the host tail
+        from manuscript_ocr_amd import ops as _ops
+        real = _ops.east_box_tail
+
+        def refusing(*args, **kw):
+            out, n = real(*args, **kw)
+            n[0] = -1
+            return out, n
+
+        det.device_tail = True
+        _ops.east_box_tail = refusing
+        try:
+            c = det.predict_batch(pages, _maps_override=mo)
+        finally:
+            _ops.east_box_tail = real
+        for rc, rb in zip(c, b):
+            assert [(w.polygon, w.detection_confidence) for w in rc["page"].blocks[0].words] == \
+                   [(w.polygon, w.detection_confidence) for w in rb["page"].blocks[0].words]
