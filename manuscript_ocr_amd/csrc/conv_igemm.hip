@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "internal.h"
 #include "msocr.h"
 
@@ -88,14 +90,18 @@ __device__ __forceinline__ int swz(int row) {
 // LEAN: 1x1 kernel without padding (every 1x1 convolution and the batched GEMMs of the Winograd path) — a K-tile is a plain
 // pointer increment, no tap decoding, no bounds masks (rows >= M load valid garbage that the epilogue never stores).  PMC on
 // the Winograd GEMM counted 1.9 VALU + 1.2 SALU instructions per MFMA in the general loader; they share the SIMD's issue port.
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32>
 __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
   constexpr int EPC = 16 / ES;   // elements per chunk
   constexpr int BK = BKB / ES;
   constexpr int WAVES_N = BN / WN;
-  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(MT == 32 || (MT == 16 && sizeof(T) == 4), "16x16x4 is the f32 shape");
+  constexpr int TM = WM / MT, TN = WN / MT;
+  constexpr int AE = MT == 32 ? 16 : 4;
+  constexpr int CQ = 64 / MT;
+  using AccT = typename std::conditional<MT == 32, f32x16, f32x4>::type;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
   constexpr int RPP = 256 / CPR;  // tile rows covered per pass of 256 threads
   constexpr int A_IT = BM / RPP;
@@ -207,62 +213,78 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
     }
   };
 
-  f32x16 acc[TM][TN];
+  AccT acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
-  const int r32 = lane & 31, half = lane >> 5;
+  const int r32 = lane & (MT - 1), half = lane / MT;
 
   load_tile(0);
   store_tile(0);
   __syncthreads();
 
   auto read_frags = [&](const unsigned char* sa, const unsigned char* sb, int q, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
-    const int c = 2 * q + half;
+    const int c = CQ * q + half;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row = wm * WM + i * 32 + r32;
+      const int row = wm * WM + i * MT + r32;
       fa[i] = *reinterpret_cast<const u32x4*>(sa + row * BKB + ((c ^ swz<BKB>(row)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int row = wn * WN + j * 32 + r32;
+      const int row = wn * WN + j * MT + r32;
       fb[j] = *reinterpret_cast<const u32x4*>(sb + row * BKB + ((c ^ swz<BKB>(row)) << 4));
     }
   };
-  constexpr int NQ = CPR / 2;
+  constexpr int NQ = CPR / CQ;
   for (int kt = 0; kt < p.ktiles; ++kt) {
     const int cur = STAGES == 1 ? 0 : (kt & 1);
     if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
-    u32x4 fa[2][TM], fb[2][TN];
-    read_frags(sa, sb, 0, fa[0], fb[0]);
+    if constexpr (MT == 16) {
+      // 16x16x4: 16 accumulator tiles per wave; fragments are read just in time (8 x b128 per 16 k), no second fragment buffer
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (q + 1 < NQ) {  // LDS reads of the next k-group are issued BEFORE this group's MFMAs and stay pinned there
-        read_frags(sa, sb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (sizeof(T) == 4) {
-        // k-element outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
+      for (int q = 0; q < NQ; ++q) {
+        u32x4 fa[TM], fb[TN];
+        read_frags(sa, sb, q, fa, fb);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[q & 1][i][e]), __uint_as_float(fb[q & 1][j][e]),
-                                                               acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+    u32x4 fa[2][TM], fb[2][TN];
+      read_frags(sa, sb, 0, fa[0], fb[0]);
+  #pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {  // LDS reads of the next k-group are issued BEFORE this group's MFMAs and stay pinned there
+          read_frags(sa, sb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (sizeof(T) == 4) {
+          // k-element outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+  #pragma unroll
+            for (int i = 0; i < TM; ++i)
+  #pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[q & 1][i][e]), __uint_as_float(fb[q & 1][j][e]),
+                                                                 acc[i][j], 0, 0, 0);
+        } else {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i)
+  #pragma unroll
+            for (int j = 0; j < TN; ++j) Mma<T>::run(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+        }
       }
     }
     if (STAGES == 1) {  // one LDS stage (3 workgroups per CU): everyone must be done reading before it is overwritten
@@ -286,17 +308,19 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 #pragma unroll
   for (int e = 0; e < EPC; ++e) bias[e] = p.bias ? p.bias[co + e] : 0.f;
 
+  constexpr int TPP = 32 / MT;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < WM / 32; ++i) {
     if (i) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int ti = 0; ti < TPP; ++ti)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int lrow = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int col = wn * WN + j * 32 + r32;
-        sc[lrow * BN + col] = acc[i][j][e];
-      }
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < AE; ++e) {
+          const int rit = MT == 32 ? (e & 3) + 8 * (e >> 2) + 4 * half : 4 * half + e;
+          sc[(wm * 32 + ti * MT + rit) * BN + wn * WN + j * MT + r32] = acc[i * TPP + ti][j][e];
+        }
     __syncthreads();
     for (int lr = vrow0; lr < PR; lr += ROWS_PP) {
       const int trow = (lr >> 5) * WM + i * 32 + (lr & 31);
@@ -337,7 +361,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -347,7 +371,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI = (BM / WM) * 32 * BN * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN>;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -371,6 +395,13 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
   if (p.Cout % 128 == 0) {
     if constexpr (sizeof(T) == 4) {
       static const int lean_on = getenv("MSOCR_CONV_LEAN") ? atoi(getenv("MSOCR_CONV_LEAN")) : 1;
+      // MT16: v_mfma_f32_16x16x4_f32 tiles (same FLOP per cycle, half the accumulator traffic per FLOP, fragments read just in
+      // time): +1-4 % on the lean GEMM launches; 2 = also the general 3x3 loader (diagnostic)
+      static const int mt16 = getenv("MSOCR_CONV_MT16") ? atoi(getenv("MSOCR_CONV_MT16")) : 1;
+      if (wide && variant == 1 && mt16 == 2 && !(lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0))
+        return launch_cfg<T, 128, 128, 128, 64, 64, 1, false, 16>(p, s);
+      if (wide && variant == 1 && lean_on && mt16 && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
+        return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16>(p, s);
       if (wide && variant == 1 && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, true>(p, s);
     }
