@@ -270,15 +270,37 @@ def bilstm_recurrent(xproj, whh_t, B, T, H):
 
 def crop_descriptors(boxes, page_ids, page_hw, img_h, img_w):
     """Host side of the device crop: clamped AABB (reference _pipeline.py:211-217) and ResizeAndPadA's size
-    arithmetic (transforms.py:91-95,114-117; Python round = banker's).  boxes: iterable of (x_min,y_min,x_max,y_max)
-    ints.  Returns (int32 [M,8] descriptors, keep mask) — empty crops are dropped like the reference does."""
+    arithmetic (transforms.py:91-95,114-117; Python round = banker's = np.rint on the same doubles).  boxes: iterable of
+    (x_min,y_min,x_max,y_max) ints.  Returns (int32 [M,8] descriptors, keep mask) — empty crops are dropped like the
+    reference does.  Vectorised; `_crop_descriptors_loop` is the literal per-box form it is tested against."""
+    import numpy as np
+    H, W = page_hw
+    b = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
+    pg = np.asarray(page_ids, dtype=np.int64).reshape(-1)
+    a_, b_ = np.maximum(0, b[:, 0]), np.maximum(0, b[:, 1])
+    c_, d_ = np.minimum(W, b[:, 2]), np.minimum(H, b[:, 3])
+    c_ = np.where(c_ < 0, np.maximum(W + c_, 0), c_)  # Python slice semantics of image[y1:y2, x1:x2] with a negative stop
+    d_ = np.where(d_ < 0, np.maximum(H + d_, 0), d_)
+    keep = (c_ > a_) & (d_ > b_)
+    a_, b_, c_, d_, pg = a_[keep], b_[keep], c_[keep], d_[keep], pg[keep]
+    h, w = d_ - b_, c_ - a_
+    scale = np.minimum(img_h / np.maximum(h, 1), img_w / np.maximum(w, 1))  # float64, as Python's min of two true divisions
+    nw = np.maximum(1, np.rint(w * scale).astype(np.int64))
+    nh = np.maximum(1, np.rint(h * scale).astype(np.int64))
+    yy = np.maximum(0, np.minimum((img_h - nh) // 2, img_h - nh))
+    desc = np.stack([pg, a_, b_, c_, d_, nw, nh, yy], axis=1).astype(np.int32) if len(pg) else np.zeros((0, 8), dtype=np.int32)
+    return desc, keep
+
+
+def _crop_descriptors_loop(boxes, page_ids, page_hw, img_h, img_w):
+    """Literal per-box form of `crop_descriptors` (kept for the differential CPU test)."""
     import numpy as np
     H, W = page_hw
     desc, keep = [], []
     for (x0, y0, x1, y1), pg in zip(boxes, page_ids):
         a, b = max(0, int(x0)), max(0, int(y0))
         c, d = min(W, int(x1)), min(H, int(y1))
-        if c < 0:  # Python slice semantics of image[y1:y2, x1:x2] with a negative stop
+        if c < 0:
             c = max(W + c, 0)
         if d < 0:
             d = max(H + d, 0)

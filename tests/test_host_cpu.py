@@ -336,3 +336,24 @@ def test_box_tail_host_twin_equals_numpy_tail():
         rc = nat.lib().msocr_east_box_tail_host(np.ascontiguousarray(q).ctypes.data, M, ew, eh, ohw[1] / twh[0], ohw[0] / twh[1], int(aa), int(anom),
                                                 5.0, minc, out.ctypes.data, ctypes.byref(n))
         assert rc == 0 and n.value == len(e) and np.array_equal(out[: n.value], e), (trial, M)
+
+
+def test_vectorised_crop_descriptors_equal_the_loop():
+    """ops.crop_descriptors (NumPy) == the literal per-box arithmetic (clamping incl. Python's negative-stop slices, min of the
+    two scale factors, banker's rounding of the new size, vertical centring), on boxes inside, across and outside the page."""
+    from manuscript_ocr_amd import ops
+    rng = np.random.default_rng(17)
+    for img_h, img_w in ((32, 100), (64, 256), (32, 128)):
+        for trial in range(20):
+            n = int(rng.integers(1, 300))
+            x0, y0 = rng.integers(-60, 2100, size=n), rng.integers(-60, 1600, size=n)
+            w, h = rng.integers(-5, 400, size=n), rng.integers(-5, 120, size=n)
+            boxes = [(int(a), int(b), int(a + c), int(b + d)) for a, b, c, d in zip(x0, y0, w, h)]
+            if trial % 4 == 0:  # exact .5 cases for the rounding rule: new size = k + 0.5 before rounding
+                boxes += [(0, 0, 200, 20), (10, 10, 10 + 64, 10 + 13), (0, 0, 3, 64), (5, 5, 5 + 8, 5 + 5)]
+            pids = [int(p) for p in rng.integers(0, 4, size=len(boxes))]
+            d1, k1 = ops.crop_descriptors(boxes, pids, (1536, 2048), img_h, img_w)
+            d2, k2 = ops._crop_descriptors_loop(boxes, pids, (1536, 2048), img_h, img_w)
+            assert np.array_equal(k1, k2) and d1.dtype == d2.dtype and np.array_equal(d1, d2)
+    d, k = ops.crop_descriptors([], [], (100, 100), 32, 100)
+    assert d.shape == (0, 8) and k.shape == (0,)
