@@ -245,8 +245,20 @@ def main():
         res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}
         res["east_stage_s_last_step"] = {k: round(v, 4) for k, v in det.last_profile.items()}
     if rank == 0 and not a.no_roofline:
-        # Live HIP-event timing of every implicit-GEMM launch (events on the launch stream = torch's current stream).
+        # Live HIP-event timing of every hot-path launch (events on the launch stream = torch's current stream); records are
+        # (start, end, kind, work, tag), see manuscript_ocr_amd/ops.py::PROFILE.
         peak = PEAK_TFLOPS[a.precision]
+
+        def union_ms(iv):
+            iv = sorted(iv)
+            tot, cs, ce = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > ce:
+                    tot += ce - cs
+                    cs, ce = s_, e_
+                else:
+                    ce = max(ce, e_)
+            return tot + ce - cs
 
         def instrumented(serialize):
             if pipe is not None:
@@ -256,65 +268,101 @@ def main():
             ref = torch.cuda.Event(enable_timing=True)
             ref.record()
             ops.PROFILE = []
+            if rec is not None:
+                rec.last_run_length_sum = rec.last_rows = 0
             run_steps(a.steps)
             torch.cuda.synchronize()
             prof, ops.PROFILE = ops.PROFILE, None
             if pipe is not None:
                 pipe.serialize_streams = a.serialize_streams
-            iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1, _, _ in prof)
-            fl = float(sum(f for _, _, f, _ in prof))
-            instrumented.executed = float(sum(t[4] for _, _, _, t in prof))
-            dur = np.array([e - s for s, e in iv])
-            union, cs, ce = 0.0, iv[0][0], iv[0][1]
-            for s_, e_ in iv[1:]:
-                if s_ > ce:
-                    union += ce - cs
-                    cs, ce = s_, e_
-                else:
-                    ce = max(ce, e_)
-            union += ce - cs
-            return prof, fl, dur, union
+            by = {}
+            for e0, e1, kind, work, tag in prof:
+                by.setdefault(kind, []).append((ref.elapsed_time(e0), ref.elapsed_time(e1), work, tag))
+            return by
 
-        # (1) the timed configuration: sub-batch streams overlap, so a launch's event-to-event time includes the other
-        #     streams' kernels sharing the chip.  Chip-level rate = FLOP / union of the intervals in which >= 1 conv runs.
-        prof, fl, dur, union = instrumented(a.serialize_streams)
-        tf = fl / (union * 1e-3) / 1e12
+        CONV = ("conv_gemm", "wino_in", "wino_out")
+        # (1) the timed configuration: sub-batch streams overlap, so a launch's event-to-event time includes the other streams'
+        #     kernels sharing the chip.  Chip-level rate = FLOP / union of the intervals in which >= 1 conv-stage kernel runs.
+        by = instrumented(a.serialize_streams)
+        gemm = by["conv_gemm"]
+        executed = float(sum(w[1] for _, _, w, _ in gemm))
+        algorithmic = float(sum(w[0] for _, _, w, _ in gemm))
+        stage_ms = union_ms([(s_, e_) for k in CONV for s_, e_, _, _ in by.get(k, [])])
+        gemm_ms = union_ms([(s_, e_) for s_, e_, _, _ in gemm])
         res["roofline"] = {
-            "kernel": "convolution stage = every msocr_conv2d / msocr_conv3x3_winograd call of a step (conv_igemm_kernel, plus the "
-                      "two Winograd transform kernels around its 16-GEMM launch); achieved = ALGORITHMIC direct-convolution FLOP "
-                      "(2*MACs, SURVEY.md 8d) / time in which at least one such call is executing, sub-batch streams overlapping as "
-                      "in the timed region.  Winograd F(2x2,3x3) executes 2.25x fewer matrix FLOPs than the algorithmic count on "
-                      "the 3x3/1/1 layers, so `achieved` may approach or pass the MFMA peak; `executed_mfma_tflops` is what the "
-                      "matrix pipes really run",
+            "kernel": "conv_igemm_kernel (implicit-GEMM convolution on the f32 matrix cores: direct convolutions, 1x1 layers, the "
+                      "LSTM/linear GEMMs and the 16-GEMM launch of every Winograd F(2x2,3x3) layer), over the convolution stage = "
+                      "those launches + the Winograd transform kernels around them",
             "bound": "mfma",
-            "achieved": tf,
-            "executed_mfma_tflops": instrumented.executed / (union * 1e-3) / 1e12,
-            "executed_frac_of_peak": instrumented.executed / (union * 1e-3) / 1e12 / peak,
+            "achieved": executed / (stage_ms * 1e-3) / 1e12,
             "peak": peak,
             "unit": "TFLOP/s",
-            "frac": tf / peak,
-            "traffic": pmc_traffic() if (a.workload == "pipeline" and a.precision == "fp32" and not a.pages and not a.sub_batches) else None,
-            "launches_per_step": len(prof) // a.steps,
-            "avg_launch_ms": float(dur.mean()),
-            "conv_busy_ms_per_step": float(union / a.steps),
-            "alg_gflop_per_step": fl / a.steps / 1e9,
+            "frac": executed / (stage_ms * 1e-3) / 1e12 / peak,
+            "definition": "achieved = FLOP the MFMAs EXECUTE (Winograd layers: 2*16*tiles*Cin*Cout, 2.25x fewer than the direct "
+                          "form) / time in which at least one conv-stage kernel is executing (HIP events on the launch streams, "
+                          "sub-batch streams overlapping as in the timed region); <= 1 by construction",
+            "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": executed / (gemm_ms * 1e-3) / 1e12 / peak,
+                                 "busy_ms_per_step": gemm_ms / a.steps},
+            "algorithmic_equiv_tflops": algorithmic / (stage_ms * 1e-3) / 1e12,
+            "traffic": None,
+            "traffic_from_profile": pmc_traffic() if (a.workload == "pipeline" and a.precision == "fp32" and not a.pages
+                                                      and not a.sub_batches) else None,
+            "launches_per_step": len(gemm) // a.steps,
+            "conv_stage_busy_ms_per_step": stage_ms / a.steps,
+            "executed_gflop_per_step": executed / a.steps / 1e9,
+            "alg_gflop_per_step": algorithmic / a.steps / 1e9,
         }
-        # (2) the same launches on ONE stream: isolated per-launch durations (FLOP-weighted rate of a launch running alone)
+        # (2) the same launches on ONE stream: isolated per-launch durations -> per-kernel rooflines (FLOP or algorithmic bytes /
+        #     sum of the launch durations), comparable one to one with the rocprofv3 --kernel-trace --stats averages in profiles/
         if pipe is not None and not a.serialize_streams:
-            prof2, fl2, dur2, _ = instrumented(True)
-            tf2 = fl2 / (dur2.sum() * 1e-3) / 1e12
-            res["roofline"]["isolated"] = {"achieved": tf2, "frac": tf2 / peak, "avg_launch_ms": float(dur2.mean()),
-                                           "conv_ms_per_step": float(dur2.sum() / a.steps)}
+            by = instrumented(True)
+        gemm = by["conv_gemm"]
+        dur = np.array([e_ - s_ for s_, e_, _, _ in gemm])
+        ex2 = float(sum(w[1] for _, _, w, _ in gemm))
+        res["roofline"]["isolated"] = {"achieved": ex2 / (dur.sum() * 1e-3) / 1e12, "frac": ex2 / (dur.sum() * 1e-3) / 1e12 / peak,
+                                       "avg_launch_ms": float(dur.mean()), "gemm_ms_per_step": float(dur.sum() / a.steps),
+                                       "conv_stage_ms_per_step": float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])) / a.steps)}
+        HBM_PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
+        names = {"wino_in": "wino_input_kernel", "wino_out": "wino_output_kernel", "se_residual": "se_residual_kernel",
+                 "maxpool": "maxpool_kernel", "bilstm": "bilstm_kernel", "attn_beam": "attn_beam_mfma_kernel"}
+        mean_run = (rec.last_run_length_sum / rec.last_rows) if (rec is not None and getattr(rec, "last_rows", 0)) else None
+        sec = []
+        for kind, kname in names.items():
+            recs = by.get(kind)
+            if not recs:
+                continue
+            d_ms = np.array([e_ - s_ for s_, e_, _, _ in recs])
+            ent = {"kernel": kname, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK, "launches_per_step": len(recs) // a.steps,
+                   "avg_launch_ms": float(d_ms.mean())}
+            if kind in ("bilstm", "attn_beam"):
+                # recurrent kernels: SURVEY.md 8d bytes per step x steps the launch runs (beam: the chunks' mean run length)
+                steps_run = [(w[1] if kind == "bilstm" or mean_run is None else min(w[1], mean_run)) for _, _, w, _ in recs]
+                nbytes = float(sum(w[0] * st if kind == "attn_beam" else w[0] for (_, _, w, _), st in zip(recs, steps_run)))
+                ent["steps_per_s"] = float(sum(steps_run) / (d_ms.sum() * 1e-3))
+                ent["step_latency_us"] = float(d_ms.sum() * 1e3 / sum(steps_run))
+                ent["note"] = ("latency-bound by design (SURVEY.md 8d): weights stay in L2/LDS, the algorithmic bytes per step "
+                               "would take ~2 us at the HBM roof")
+            else:
+                nbytes = float(sum(w for _, _, w, _ in recs))
+            ent["alg_bytes_per_launch"] = nbytes / len(recs)
+            ent["achieved"] = nbytes / (d_ms.sum() * 1e-3) / 1e9
+            ent["frac"] = ent["achieved"] / HBM_PEAK
+            sec.append(ent)
+        res["roofline"]["secondary"] = sec
         if os.environ.get("MSOCR_DUMP_CONV"):
             agg = {}
-            for (e0, e1, f, tag) in prof:
-                a_ = agg.setdefault(tag[:4], [0, 0.0, 0.0])
+            for s_, e_, w, tag in gemm:
+                a_ = agg.setdefault(tag, [0, 0.0, 0.0, 0.0])
                 a_[0] += 1
-                a_[1] += e0.elapsed_time(e1)
-                a_[2] += f
+                a_[1] += e_ - s_
+                a_[2] += w[0]
+                a_[3] += w[1]
             with open(os.environ["MSOCR_DUMP_CONV"], "w") as fh:
-                for tag, (cnt, m, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} {tag[3]} calls={cnt} ms={m:.3f} TF/s={f / (m * 1e-3) / 1e12:.1f}\n")
+                fh.write("# per conv shape, isolated launches (one stream), %d steps: M N K path calls ms_per_step alg_TFLOPs executed_TFLOPs\n" % a.steps)
+                for tag, (cnt, m, f, fe) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} {tag[3]} calls_per_step={cnt / a.steps:g} ms_per_step={m / a.steps:.3f} "
+                             f"alg_TF/s={f / (m * 1e-3) / 1e12:.1f} executed_TF/s={fe / (m * 1e-3) / 1e12:.1f}\n")
+        res["max_memory_reserved_gb"] = torch.cuda.max_memory_reserved() / 2 ** 30
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out, target_wh=(TW, TH))
@@ -328,15 +376,19 @@ def main():
 
 
 def pmc_traffic():
-    """HBM bytes per step of the convolution stage (conv_igemm_kernel + Winograd transforms) from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
-    rocprofv3 --pmc passes of this same command; bench.py cannot run the profiler on itself, so the committed
-    measurement is reported, or null when absent / not for this workload)."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_step"])
-    except Exception:
-        return None
+    """HBM bytes per step of the convolution stage from the PMC counters — NOT measured in this run: bench.py cannot run the
+    profiler on itself, so the newest committed measurement (separate rocprofv3 --pmc passes of this same command: FETCH_SIZE x2
+    on gfx950 + WRITE_SIZE) is quoted with its source, under `traffic_from_profile`; the live `traffic` stays null."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                return {"hbm_bytes_per_step": float(json.load(f)["hbm_bytes_per_step"]), "source": os.path.relpath(path, ROOT),
+                        "measured_in_this_run": False}
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budget_s=12.0, target_wh=None):
@@ -360,6 +412,7 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     L.lib()
     n, t0 = 0, time.perf_counter()
     edits = chars = mism = n_words = n_diff = n_tie = 0
+    sample_crops = None
     with torch.no_grad():
         for pi, (pg, s, g) in enumerate(zip(pages, scores, geos)):
             net(torch.from_numpy(imgproc.east_preprocess(pg, TW, TH)))
@@ -373,8 +426,18 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
                     lg, ids = tnet(x, max_len=25, mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
                     res += otm.texts_and_confidences(lg, ids, itos, 0, 2, None)
                 gw = [w for w in gpu_pages[pi].blocks[0].words]
-                gtexts = [gw[pos].text for pos in kept] if len(gw) == len(order) else []
-                mism += int(len(gw) != len(order))
+                if len(gw) != len(order):  # different box sets: every CPU word of the page counts as fully wrong
+                    mism += 1
+                    for r in res:
+                        edits += max(len(r["text"]), 1)
+                        chars += max(len(r["text"]), 1)
+                        n_words += 1
+                        n_diff += 1
+                    n += 1
+                    continue
+                gtexts = [gw[pos].text for pos in kept]
+                if sample_crops is None:
+                    sample_crops = crops
                 for r, hyp in zip(res, gtexts):
                     ref_t, hyp = r["text"], hyp or ""
                     edits += _lev(ref_t, hyp)
@@ -388,7 +451,12 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
             if time.perf_counter() - t0 > budget_s:
                 break
     el = time.perf_counter() - t0
+    extra = {}
+    if workload == "pipeline" and sample_crops:
+        extra["random_weight_decoder"] = random_weight_leg(sample_crops[:256], itos)
+    extra["real_network_chain"] = real_network_leg(esd, net, pages[0])
     return {
+        **extra,
         "value": n / el,
         "unit": "pages/s",
         "cores": torch.get_num_threads(),
@@ -401,6 +469,66 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
         "words_differing_at_cpu_near_tie": n_tie,  # first-character margin < TIE_TOL in the CPU path's own logits
         "box_count_mismatch_pages": mism,
     }
+
+
+def random_weight_leg(crops, itos):
+    """Text parity where it is hardest: the same word crops through an ALL-RANDOM-weights recogniser (every character an arg-max
+    over near-Gaussian logits, x6 recurrent gain) on the device and in the CPU oracle, beam-8, compared row by row with the
+    first-differing-step near-tie rule (oracle/decode_check.py).  Outside the timed region and outside cpu_baseline.value."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import decode_check, imgproc
+    from oracle import trba_model as otm
+    sd = synth.trba_state_dict(194, 256, seed=20260128)
+    rec = TRBA(state_dict=sd, config=TRBA_CFG, device="cuda")
+    canv = np.stack([imgproc.resize_and_pad(np.ascontiguousarray(c), 32, 100) for c in crops])
+    ids, trun, conf, lg = rec.recognize_canvases(torch.from_numpy(canv).cuda(), batch_size=32, mode="beam", return_logits=True)
+    net = otm.TRBANet(194, 256)
+    net.load_state_dict(sd)
+    net.eval()
+    x = torch.from_numpy(((canv.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
+    exp = decode_check.oracle_decode_chunks(net, x, "beam")
+    rep = decode_check.compare_decodes(ids, trun, lg, exp, "beam", logit_rtol=3e-2)
+    got_t = rec.texts(ids, trun)
+    exp_t = [otm.decode_tokens(e["ids"], itos, 0, 2, None) for e in exp]
+    edits = sum(_lev(a, b) for a, b in zip(exp_t, got_t))
+    return {"weights": "synth.trba_state_dict (all random)", "words_compared": len(exp), "rows_identical_ids": len(rep["same"]),
+            "words_differing": sum(a != b for a, b in zip(exp_t, got_t)),
+            "rows_differing_at_cpu_near_tie": len(rep["ties"]) + len(rep["run_length_only"]),
+            "rows_differing_not_at_a_tie": len(rep["hard"]),
+            "near_tie_margins": [round(float(t[3]), 6) for t in rep["ties"] if t[3] is not None],
+            "tie_tol": decode_check.TIE_TOL, "cer_gpu_vs_cpu": edits / max(1, sum(max(len(t), 1) for t in exp_t)),
+            "logit_err_rel_p90": float(np.quantile(rep["row_logit_err_rel"], 0.9)), "logit_err_rel_max": rep["max_logit_err_rel"]}
+
+
+def real_network_leg(esd, oracle_net, page, hw=(256, 384)):
+    """EAST forward -> decode -> LANMS -> filters with the maps of the REAL network on both sides (no injection), on a small
+    window of the page: device chain vs oracle chain.  Random weights give meaningless but deterministic boxes; the two
+    chains see maps that differ by f32 rounding, so boxes are matched within a pixel tolerance, not bit for bit."""
+    from manuscript_ocr_amd.detectors import EAST
+    from oracle import east_post as P
+    from oracle import imgproc
+    from oracle import lanms as L
+    h, w = hw
+    win = np.ascontiguousarray(page[:h, :w])
+    det = EAST(state_dict=esd, target_size=(w, h), device="cuda")
+    out = det.predict(win, return_maps=True)
+    got = np.array([[c for pt in wd.polygon for c in pt] for wd in out["page"].blocks[0].words], dtype=np.float32).reshape(-1, 8)
+    with torch.no_grad():
+        r = oracle_net(torch.from_numpy(imgproc.east_preprocess(win, w, h)))
+    rs, rg = r["score"][0, 0].numpy(), r["geometry"][0].permute(1, 2, 0).contiguous().numpy()
+    exp = P.east_postprocess(rs, rg, (h, w), (w, h), L.locality_aware_nms)[:, :8]
+    matched, worst = 0, 0.0
+    for q in got:
+        if len(exp):
+            dd = np.abs(exp - q).max(axis=1)
+            if dd.min() < 0.5:
+                matched += 1
+                worst = max(worst, float(dd.min()))
+    return {"window_hw": list(hw), "score_max_abs_err": float(np.abs(out["score_map"] - rs).max()),
+            "geo_max_abs_err": float(np.abs(out["geo_map"] - rg.transpose(2, 0, 1)).max()),
+            "boxes_gpu": int(len(got)), "boxes_cpu": int(len(exp)), "boxes_matched_within_half_px": matched,
+            "max_coord_diff_of_matched_px": worst}
 
 
 def _lev(a, b):

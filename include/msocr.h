@@ -66,6 +66,13 @@ int64_t msocr_conv3x3_winograd_workspace_bytes(const msocr_conv_desc* d);
 int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
                            const void* residual, void* out, void* workspace, void* stream);
 int msocr_winograd_weights_host(const float* w_khwc_host, int Cout, int Cin, float* u_out_host);
+/* The three stages of msocr_conv3x3_winograd one by one (identical kernels, identical results when called in this order on one
+ * stream with the same workspace): V = B^T d B into the workspace; Mw[p] = V[p] U[p]^T (16 GEMMs, one MFMA launch);
+ * out = act(A^T Mw A + bias (+ residual)).  For tests and for the per-kernel rooflines of bench.py. */
+int msocr_winograd_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream);
+int msocr_winograd_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream);
+int msocr_winograd_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
+                                    void* out, void* stream);
 
 /* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->cpad (4 or 8) inside a zero canvas
  * out[N][Hp][Wp][cpad], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
@@ -111,10 +118,11 @@ int msocr_east_lanms(const float* cand, const int32_t* counts, int N, int max_ca
  * NumPy's f32 operation order: bit-identical to the host implementation.  expand_w/h, scale_x = orig_w / target_w,
  * scale_y = orig_h / target_h and sigma are the Python floats of the reference (rounded to f32 where NumPy does).
  * msocr_east_box_tail: one workgroup per page on boxes [N][max_cand][9] / nbox [N] from msocr_east_lanms ->
- * out [N][max_cand][9], n_out [N] (-1 for a page with more than 2048 boxes: use the host path); workspace:
- * msocr_east_box_tail_workspace_bytes(N) bytes.
+ * out [N][max_cand][9], n_out [N] (-1 for a page with more than min(max_cand, 16384) boxes: use the host path; pages above
+ * 2048 boxes keep their per-box arrays in the workspace instead of LDS); workspace:
+ * msocr_east_box_tail_workspace_bytes(N, max_cand) bytes.
  * msocr_east_box_tail_host: HOST twin running the same code on the CPU (quads_host [M][9] -> out_host [<=M][9], *n_out_host). */
-int64_t msocr_east_box_tail_workspace_bytes(int N);
+int64_t msocr_east_box_tail_workspace_bytes(int N, int max_cand);
 int msocr_east_box_tail(const float* boxes, const int32_t* nbox, int N, int max_cand, double expand_w, double expand_h,
                         double scale_x, double scale_y, int axis_aligned_output, int remove_anomalies, double sigma, int min_count,
                         float* out, int32_t* n_out, void* workspace, void* stream);
@@ -193,7 +201,9 @@ int msocr_seq_confidence(const float* logits, const int32_t* ids, const int32_t*
  * INTER_AREA if any axis shrinks else INTER_LINEAR, pasted at x=0 / vertically centred on a 255 canvas).
  * pages [N][H][W][3] u8; descriptor per crop = 8 x int32 {page, x1, y1, x2, y2, new_w, new_h, y0} (the host
  * evaluates Python's banker's rounding of the new size); desc_host is the same array in host memory, used only
- * to validate bounds before the launch.  canvases [M][img_h][img_w][3] u8.  (cv2 restated: parity unpinned.) */
+ * to validate bounds before the launch, or NULL when the descriptors were produced on the device
+ * (msocr_reading_order_crops): the kernel then checks every descriptor itself and emits a white canvas for an
+ * invalid one.  canvases [M][img_h][img_w][3] u8.  (cv2 restated: parity unpinned.) */
 int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32_t* desc_dev,
                           const int32_t* desc_host, int M, int img_h, int img_w, uint8_t* canvases, void* stream);
 
@@ -205,6 +215,21 @@ int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32
  * reference's dict semantics produce them). */
 int msocr_reading_order_host(const int32_t* boxes_host, int n, double y_tol_ratio, double x_gap_ratio,
                              int32_t* order_out_host);
+
+/* The same glue ON THE DEVICE, one workgroup per page, fed by msocr_east_box_tail's output, plus what follows it on the way to the
+ * recogniser: word AABBs with np.int32 truncation and the min_text_size filter (_pipeline.py:100-133), the clamped crop window
+ * (_pipeline.py:204-221) and ResizeAndPadA's size arithmetic (recognizers/_trba/data/transforms.py:91-95,114-117) -> descriptors in
+ * the format of msocr_crop_resize_pad.  boxes [N][max_cand][9] f32, nbox [N] (negative: page skipped, ncrop = -1).
+ * order_out [N][max_cand]: entry k = index of the word at reading-order position k; keep_out [N][max_cand]: 1 where position k
+ * yields a crop; desc_out [N][max_cand][8]: the page's crop descriptors in order, compacted (page field = page_base + n);
+ * ncrop_out [N]: crops of the page, or -1 = take the host path for this page (more than min(max_cand, 16384) boxes, more than
+ * 4096 text lines, or more intersecting box pairs than the pair buffer holds).  Bit-identical to msocr_reading_order_host + the
+ * host descriptor arithmetic.  workspace: msocr_reading_order_workspace_bytes(N, max_cand) bytes, 16-B aligned. */
+int64_t msocr_reading_order_workspace_bytes(int N, int max_cand);
+int msocr_reading_order_crops(const float* boxes, const int32_t* nbox, int N, int max_cand, int page_h, int page_w,
+                              int min_text_size, int img_h, int img_w, double y_tol_ratio, double x_gap_ratio, int page_base,
+                              int32_t* order_out, int32_t* keep_out, int32_t* desc_out, int32_t* ncrop_out, void* workspace,
+                              void* stream);
 
 /* f32 <-> bf16 / layout helpers */
 int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int W, int dtype, void* out, int64_t out_ld,

@@ -39,6 +39,9 @@ _SIGS = {
     "msocr_conv3x3_winograd_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd_weights_host": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "msocr_winograd_input_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),
@@ -58,10 +61,13 @@ _SIGS = {
     "msocr_attn_beam_finalize": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "msocr_seq_confidence": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_crop_resize_pad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "msocr_east_box_tail_workspace_bytes": (c_i64, [c_i32]),
+    "msocr_east_box_tail_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "msocr_east_box_tail": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_i32, c_f64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "msocr_east_box_tail_host": (c_i32, [c_vp, c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_i32, c_f64, c_i32, c_vp, c_vp]),
     "msocr_reading_order_host": (c_i32, [c_vp, c_i32, c_f64, c_f64, c_vp]),
+    "msocr_reading_order_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "msocr_reading_order_crops": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32,
+                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_nchw_f32_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "msocr_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "msocr_version": (ctypes.c_char_p, []),

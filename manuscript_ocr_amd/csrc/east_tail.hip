@@ -227,36 +227,47 @@ extern "C" int msocr_east_box_tail_host(const float* quads_host, int M, double e
 
 // ---- device: one 256-thread workgroup per page ------------------------------------------------------------------------
 namespace {
-constexpr int TAIL_MAXM = 2048;               // boxes per page the device path handles (more: n_out = -1, host path)
-constexpr int TAIL_W = TAIL_MAXM / 32;        // 32-bit words per row of the containment matrix
+constexpr int TAIL_LDSM = 2048;               // boxes per page whose per-box arrays fit the workgroup's LDS
+constexpr int TAIL_CAPM = 16384;              // boxes per page the device path handles at all (more: n_out = -1, host path)
+constexpr int TAIL_KW = TAIL_CAPM / 32 / 64;  // keep-mask words per lane of the greedy wave
+
+// per-page workspace: containment matrix [cap][cap/32] u32, then (pages above TAIL_LDSM boxes only) the per-box arrays
+__host__ __device__ inline int tail_cap(int max_cand) { return ((max_cand < TAIL_CAPM ? max_cand : TAIL_CAPM) + 31) & ~31; }
+__host__ __device__ inline long tail_ws_words(int cap) { return (long)cap * (cap / 32) + (long)cap * 16; }
 
 __global__ __launch_bounds__(256) void east_box_tail_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ nbox,
-                                                             int max_cand, TailParams p, float* __restrict__ out,
-                                                             int32_t* __restrict__ n_out, uint32_t* __restrict__ inside_ws) {
+                                                             int max_cand, int cap, TailParams p, float* __restrict__ out,
+                                                             int32_t* __restrict__ n_out, uint32_t* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Q = lds;                                   // [M][9]
-  float* area = Q + TAIL_MAXM * 9;                  // [M]
-  float* bb = area + TAIL_MAXM;                     // [M][4]
-  int* order = reinterpret_cast<int*>(bb + TAIL_MAXM * 4);  // [M]
-  int* kept = order + TAIL_MAXM;                    // [M]
-  __shared__ uint32_t keepbits[TAIL_W];
+  __shared__ uint32_t keepbits[TAIL_CAPM / 32];
   __shared__ int s_n;
   const int pg = blockIdx.x, tid = threadIdx.x;
   const int M = nbox[pg];
   float* ob = out + (long)pg * max_cand * 9;
-  if (M > TAIL_MAXM || M < 0) {
+  if (M > cap || M < 0) {
     if (tid == 0) n_out[pg] = -1;
     return;
   }
+  const int capw = cap / 32;
+  uint32_t* inside = ws + (long)pg * tail_ws_words(cap);
+  // per-box arrays: LDS for ordinary pages, the (L2-resident) workspace for pages above TAIL_LDSM boxes
+  float* base = M <= TAIL_LDSM ? lds : reinterpret_cast<float*>(inside + (long)cap * capw);
+  const int am = M <= TAIL_LDSM ? TAIL_LDSM : cap;
+  float* Q = base;                                  // [am][9]
+  float* area = Q + (long)am * 9;                   // [am]
+  float* bb = area + am;                            // [am][4]
+  int* order = reinterpret_cast<int*>(bb + (long)am * 4);  // [am]
+  int* kept = order + am;                           // [am]
   const float* ib = boxes + (long)pg * max_cand * 9;
-  uint32_t* inside = inside_ws + (long)pg * TAIL_MAXM * TAIL_W;
   const int W = (M + 31) >> 5;
   for (int i = tid; i < M; i += 256) {
     expand_scale(ib + 9 * i, p, Q + 9 * i);
     area[i] = quad_area(Q + 9 * i);
     quad_bbox(Q + 9 * i, bb + 4 * i);
   }
-  if (tid < TAIL_W) keepbits[tid] = tid < W ? (tid == W - 1 && (M & 31) ? ((1u << (M & 31)) - 1u) : 0xffffffffu) : 0u;
+  for (int w = tid; w < TAIL_CAPM / 32; w += 256)
+    keepbits[w] = w < W ? (w == W - 1 && (M & 31) ? ((1u << (M & 31)) - 1u) : 0xffffffffu) : 0u;
+  __threadfence();
   __syncthreads();
   if (M > 1) {
     // stable ascending order of the areas: rank = number of boxes that sort before box i
@@ -274,19 +285,29 @@ __global__ __launch_bounds__(256) void east_box_tail_kernel(const float* __restr
         const int j = 32 * w + b;
         if (j < M && j != i && quad_contained(Q + 9 * i, bb + 4 * i, area[i], Q + 9 * j, bb + 4 * j, area[j])) bits |= 1u << b;
       }
-      inside[(long)i * TAIL_W + w] = bits;
+      inside[(long)i * capw + w] = bits;
     }
     __threadfence();
     __syncthreads();
-    // greedy pass in ascending-area order (infer.py:203-213): one wave, lane l owns word l of the keep mask
+    // greedy pass in ascending-area order (infer.py:203-213): one wave, lane l owns words l, l+64, ... of the keep mask
     if (tid < 64) {
-      uint32_t mykeep = tid < TAIL_W ? keepbits[tid] : 0u;
+      uint32_t mykeep[TAIL_KW];
+#pragma unroll
+      for (int k = 0; k < TAIL_KW; ++k) mykeep[k] = keepbits[tid + 64 * k];
       for (int r = 0; r < M; ++r) {
         const int i = order[r];
-        const uint32_t v = tid < W ? (inside[(long)i * TAIL_W + tid] & mykeep) : 0u;
-        if (__any(v != 0u) && tid == (i >> 5)) mykeep &= ~(1u << (i & 31));
+        uint32_t v = 0u;
+#pragma unroll
+        for (int k = 0; k < TAIL_KW; ++k)
+          if (tid + 64 * k < W) v |= inside[(long)i * capw + tid + 64 * k] & mykeep[k];
+        if (__any(v != 0u)) {
+#pragma unroll
+          for (int k = 0; k < TAIL_KW; ++k)
+            if (tid + 64 * k == (i >> 5)) mykeep[k] &= ~(1u << (i & 31));
+        }
       }
-      if (tid < TAIL_W) keepbits[tid] = mykeep;
+#pragma unroll
+      for (int k = 0; k < TAIL_KW; ++k) keepbits[tid + 64 * k] = mykeep[k];
     }
     __syncthreads();
   }
@@ -311,6 +332,7 @@ __global__ __launch_bounds__(256) void east_box_tail_kernel(const float* __restr
     s_n = n1;
     n_out[pg] = n1;
   }
+  __threadfence();
   __syncthreads();
   const int n = s_n;
   for (int r = tid; r < n; r += 256) {
@@ -321,8 +343,8 @@ __global__ __launch_bounds__(256) void east_box_tail_kernel(const float* __restr
 }
 }  // namespace
 
-extern "C" int64_t msocr_east_box_tail_workspace_bytes(int N) {
-  return N > 0 ? (int64_t)N * TAIL_MAXM * TAIL_W * 4 : 0;
+extern "C" int64_t msocr_east_box_tail_workspace_bytes(int N, int max_cand) {
+  return (N > 0 && max_cand > 0) ? (int64_t)N * tail_ws_words(tail_cap(max_cand)) * 4 : 0;
 }
 
 extern "C" int msocr_east_box_tail(const float* boxes, const int32_t* nbox, int N, int max_cand, double expand_w, double expand_h,
@@ -330,14 +352,14 @@ extern "C" int msocr_east_box_tail(const float* boxes, const int32_t* nbox, int 
                                    int min_count, float* out, int32_t* n_out, void* workspace, void* stream) {
   if (!boxes || !nbox || !out || !n_out || !workspace || N <= 0 || max_cand <= 0) return MSOCR_E_ARG;
   const TailParams p = make_params(expand_w, expand_h, scale_x, scale_y, axis_aligned_output, remove_anomalies, sigma, min_count);
-  const size_t ldsz = (size_t)TAIL_MAXM * (9 + 1 + 4 + 1 + 1) * 4;
+  const size_t ldsz = (size_t)TAIL_LDSM * (9 + 1 + 4 + 1 + 1) * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)east_box_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
-  MSOCR_LAUNCH(east_box_tail_kernel, dim3(N), dim3(256), ldsz, (hipStream_t)stream, boxes, nbox, max_cand, p, out, n_out,
-               (uint32_t*)workspace);
+  MSOCR_LAUNCH(east_box_tail_kernel, dim3(N), dim3(256), ldsz, (hipStream_t)stream, boxes, nbox, max_cand, tail_cap(max_cand), p, out,
+               n_out, (uint32_t*)workspace);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }

@@ -399,12 +399,18 @@ __device__ __forceinline__ AreaTab area_tab(int d, double scale, int ssize) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void crop_resize_pad_kernel(const uint8_t* __restrict__ pages, int H, int W,
+__global__ __launch_bounds__(256) void crop_resize_pad_kernel(const uint8_t* __restrict__ pages, int N, int H, int W,
                                                                const int32_t* __restrict__ desc, int img_h, int img_w,
                                                                uint8_t* __restrict__ out) {
   const int m = blockIdx.x;
   const int32_t* d = desc + (long)m * 8;
   const int pg = d[0], x1 = d[1], y1 = d[2], x2 = d[3], y2 = d[4], nw = d[5], nh = d[6], y0 = d[7];
+  // the same bounds the host wrapper checks (descriptors written by msocr_reading_order_crops never fail them)
+  if (pg < 0 || pg >= N || x1 < 0 || y1 < 0 || x2 > W || y2 > H || x2 <= x1 || y2 <= y1 || nw < 1 || nw > img_w || nh < 1 ||
+      nh > img_h || y0 < 0 || y0 + nh > img_h) {
+    for (int p = threadIdx.x; p < img_h * img_w * 3; p += blockDim.x) out[(long)m * img_h * img_w * 3 + p] = 255;
+    return;
+  }
   const int sw = x2 - x1, sh = y2 - y1;
   const uint8_t* src = pages + ((long)pg * H + y1) * W * 3 + (long)x1 * 3;
   const long rs = (long)W * 3;  // source row stride in bytes
@@ -487,12 +493,12 @@ __global__ __launch_bounds__(256) void crop_resize_pad_kernel(const uint8_t* __r
 
 extern "C" int msocr_crop_resize_pad(const uint8_t* pages, int N, int H, int W, const int32_t* desc_dev, const int32_t* desc_host,
                                      int M, int img_h, int img_w, uint8_t* canvases, void* stream) {
-  if (!pages || !desc_dev || !desc_host || !canvases || N <= 0 || H <= 0 || W <= 0 || M <= 0 || img_h <= 0 || img_w <= 0) return MSOCR_E_ARG;
-  for (int m = 0; m < M; ++m) {  // validate on the host what the kernel's indexing assumes
+  if (!pages || !desc_dev || !canvases || N <= 0 || H <= 0 || W <= 0 || M <= 0 || img_h <= 0 || img_w <= 0) return MSOCR_E_ARG;
+  for (int m = 0; desc_host && m < M; ++m) {  // validate on the host what the kernel's indexing assumes (the kernel re-checks)
     const int32_t* d = desc_host + (long)m * 8;
     if (d[0] < 0 || d[0] >= N || d[1] < 0 || d[2] < 0 || d[3] > W || d[4] > H || d[3] <= d[1] || d[4] <= d[2]) return MSOCR_E_ARG;
     if (d[5] < 1 || d[5] > img_w || d[6] < 1 || d[6] > img_h || d[7] < 0 || d[7] + d[6] > img_h) return MSOCR_E_ARG;
   }
-  MSOCR_LAUNCH(crop_resize_pad_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, pages, H, W, desc_dev, img_h, img_w, canvases);
+  MSOCR_LAUNCH(crop_resize_pad_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, pages, N, H, W, desc_dev, img_h, img_w, canvases);
   return LAUNCH_OK();
 }

@@ -146,31 +146,57 @@ extern "C" int64_t msocr_conv3x3_winograd_workspace_bytes(const msocr_conv_desc*
   return 16 * g.Mt * ((int64_t)d->Cin + d->Cout) * (int64_t)sizeof(float);
 }
 
-extern "C" int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
-                                      const void* residual, void* out, void* workspace, void* stream) {
-  WinoGeom g;
-  if (!wino_geom(d, &g) || !in || !u_weight || !out || !workspace) return MSOCR_E_ARG;
+static int wino_check(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino_geom(d, g)) return MSOCR_E_ARG;
   if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
-  if (((uintptr_t)in | (uintptr_t)u_weight | (uintptr_t)out | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  return MSOCR_OK;
+}
+
+// The three stages of msocr_conv3x3_winograd as separate entry points (same kernels): tests and the per-kernel roofline of
+// bench.py time them one by one.  V = workspace, Mw = workspace + 16 * tiles * Cin floats.
+extern "C" int msocr_winograd_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino_check(d, &g) != MSOCR_OK || !in || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const long nb_in = (g.Mt * (d->Cin / 4) + 255) / 256;
+  if (nb_in > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, (hipStream_t)stream, (const float*)in, (long)d->in_sN,
+               (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_winograd_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino_check(d, &g) != MSOCR_OK || !u_weight || !workspace) return MSOCR_E_ARG;
+  float* V = (float*)workspace;
+  return msocr_internal_gemm_f32_batched(V, u_weight, V + 16 * g.Mt * (long)d->Cin, g.Mt, d->Cout, d->Cin, 16, (hipStream_t)stream);
+}
+
+extern "C" int msocr_winograd_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
+                                               void* out, void* stream) {
+  WinoGeom g;
+  if (wino_check(d, &g) != MSOCR_OK || !out || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)out | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
   const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
   if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
   if (bias && ((uintptr_t)bias & 15)) return MSOCR_E_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  float* V = (float*)workspace;
-  float* Mw = V + 16 * g.Mt * (long)d->Cin;
-
-  const long th_in = g.Mt * (d->Cin / 4), th_out = g.Mt * (d->Cout / 4);
-  const long nb_in = (th_in + 255) / 256, nb_out = (th_out + 255) / 256;
-  if (nb_in > 0x7fffffffL || nb_out > 0x7fffffffL) return MSOCR_E_ARG;
-  MSOCR_LAUNCH(wino_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, s, (const float*)in, (long)d->in_sN, (long)d->in_sH,
-               (long)d->in_sW, d->Cin, g, V);
-  if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
-  int rc = msocr_internal_gemm_f32_batched(V, u_weight, Mw, g.Mt, d->Cout, d->Cin, 16, s);
-  if (rc != MSOCR_OK) return rc;
-  MSOCR_LAUNCH(wino_output_kernel, dim3((unsigned)nb_out), dim3(256), 0, s, (const float*)Mw, d->Cout, g, bias,
+  const long nb_out = (g.Mt * (d->Cout / 4) + 255) / 256;
+  if (nb_out > 0x7fffffffL) return MSOCR_E_ARG;
+  const float* Mw = (const float*)workspace + 16 * g.Mt * (long)d->Cin;
+  MSOCR_LAUNCH(wino_output_kernel, dim3((unsigned)nb_out), dim3(256), 0, (hipStream_t)stream, Mw, d->Cout, g, bias,
                has_res ? (const float*)residual : nullptr, (long)d->res_ld, (d->flags & MSOCR_CONV_RELU) ? 1 : 0, (float*)out,
                (long)d->out_ld);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                                      const void* residual, void* out, void* workspace, void* stream) {
+  if (!u_weight) return MSOCR_E_ARG;
+  int rc = msocr_winograd_input_transform(d, in, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  rc = msocr_winograd_gemm(d, u_weight, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  return msocr_winograd_output_transform(d, workspace, bias, residual, out, stream);
 }
 
 // U[xi*4+nu][co][c] = sum_{kh,kw} G[xi][kh] G[nu][kw] w[co][kh][kw][c], evaluated in f64 and rounded once to f32.

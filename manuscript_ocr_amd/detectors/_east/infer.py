@@ -51,7 +51,7 @@ class EAST:
         *,
         precision: str = "fp32",
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
-        max_candidates: int = 65536,
+        max_candidates: Optional[int] = None,
         use_graphs: bool = False,
     ):
         self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
@@ -88,6 +88,8 @@ class EAST:
         self.remove_area_anomalies = remove_area_anomalies
         self.anomaly_sigma_threshold = anomaly_sigma_threshold
         self.anomaly_min_box_count = anomaly_min_box_count
+        # capacity of the candidate / box buffers per page.  None = the exact upper bound of decode_quads_from_maps for the
+        # network input: one candidate per q x q cell of the 1/4-resolution map (utils.py:349-356), so decode cannot overflow
         self.max_candidates = max_candidates
         self.use_graphs = bool(use_graphs)  # hipGraph replay of the static detect sequence in detect_start (BASELINE configs[3])
         self._graphs: Dict[Any, Dict[str, Any]] = {}
@@ -98,6 +100,13 @@ class EAST:
     def _target_wh(self):
         t = self.target_size
         return (int(t), int(t)) if np.isscalar(t) else (int(t[0]), int(t[1]))
+
+    def _max_candidates(self) -> int:
+        if self.max_candidates is not None:
+            return int(self.max_candidates)
+        tw, th = self._target_wh()
+        q = max(1, int(self.quantization))
+        return max(1, (th // 4 // q) * (tw // 4 // q))
 
     def detect_device(self, pages_dev: torch.Tensor, maps_override=None):
         """pages_dev [N,h,w,3] u8 on the device (any size) -> device tensors
@@ -111,7 +120,7 @@ class EAST:
             score.copy_(maps_override[0], non_blocking=True)
             geo.copy_(maps_override[1], non_blocking=True)
         cand, counts = ops.east_decode(score, geo, self.score_thresh, 1.0 / self.score_geo_scale, self.quantization,
-                                       self.max_candidates)
+                                       self._max_candidates())
         boxes, nbox = ops.east_lanms(cand, counts, self.iou_threshold)
         fboxes = fn = None
         if getattr(self, "device_tail", True):
@@ -190,9 +199,10 @@ class EAST:
             nbox_h = nbox.cpu().numpy()
             counts_h = counts.cpu().numpy()
             if np.any(counts_h < 0):
-                raise RuntimeError(f"more than max_candidates={self.max_candidates} pixels above threshold; raise max_candidates")
+                raise RuntimeError(f"more than max_candidates={self._max_candidates()} cells above threshold; raise max_candidates "
+                                   "(None = the exact bound for the network input)")
             fn_h = fn.cpu().numpy() if fn is not None else None
-            on_device = fn_h is not None and bool(np.all(fn_h >= 0))  # a page with > 2048 boxes leaves the tail to the host
+            on_device = fn_h is not None and bool(np.all(fn_h >= 0))  # a page above the device tail capacity (16384 boxes) leaves the tail to the host
             if on_device:
                 final_h = fboxes[:, : max(int(fn_h.max()), 1)].cpu().numpy()
             else:

@@ -12,9 +12,28 @@ import torch
 from . import _native as nat
 
 
-# When set to a list, conv2d appends (start_event, end_event, algorithmic_flops, shape_tag) per launch;
-# bench.py uses it for the live HIP-event roofline of the dominant kernel.
+# When set to a list, the wrappers below append one record per kernel launch: (start_event, end_event, kind, work, tag), with
+# the events recorded on the launch stream (torch's current stream).  bench.py turns them into the live HIP-event rooflines.
+#   kind "conv_gemm": work = (algorithmic direct-convolution FLOP, FLOP the MFMAs execute), tag = (M, N, K, "direct"|"winograd")
+#   kind "wino_in" / "wino_out" / "se_residual" / "maxpool" / ...: work = algorithmic HBM bytes (bytes in + bytes out)
+#   kind "bilstm" / "attn_beam": work = (algorithmic bytes per SURVEY.md 8d, recurrent steps of the launch)
 PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, kind, work, tag=None):
+    if e0 is None or PROFILE is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((e0, e1, kind, work, tag))
 
 
 def _dt(t):
@@ -47,6 +66,29 @@ def _pixel_dense_ld(t):
 # Winograd F(2x2,3x3) for f32 3x3/1/1 convolutions with at least this many input channels (0 disables it).  Below 128
 # channels the 16 transform-domain GEMMs have K < 128 and become HBM-bound themselves.
 WINOGRAD_MIN_CIN = int(os.environ.get("MSOCR_WINOGRAD_MIN_CIN", "128"))
+
+
+# Winograd workspace (V and Mw, 16 * tiles * (Cin + Cout) f32): ONE reusable arena per launch stream, grown lazily to the
+# largest layer seen — calls on a stream are stream-ordered, so consecutive layers reuse the same bytes.  (A fresh torch.empty
+# per call left every layer's high-water block cached in every one of the 32 stream pools: 279 GB reserved at 3072x4096.)
+# Calls whose workspace would exceed WINO_WS_LIMIT are split over the batch dimension.
+WINO_WS_LIMIT = int(os.environ.get("MSOCR_WINO_WS_LIMIT", str(1 << 30)))
+_WINO_ARENA = {}
+
+
+def _wino_workspace(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():  # a hipGraph capture owns its allocations (private pool)
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WINO_ARENA.get(key)
+    if buf is None or buf.numel() < nbytes:
+        # the old block returns to the caching allocator on the stream it was allocated on: kernels already queued there
+        # finish with it before any later allocation of that stream can reuse it
+        buf = None
+        _WINO_ARENA.pop(key, None)
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _WINO_ARENA[key] = buf
+    return buf
 
 
 def attach_winograd(w):
@@ -96,26 +138,39 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout and bias.is_contiguous()
     prof = PROFILE
-    if prof is not None:  # events are recorded on the launch stream (torch's current stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     bp = bias.data_ptr() if bias is not None else None
+    alg = 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin)  # ALGORITHMIC direct-convolution FLOP (2 * MACs)
     if use_wino:
         nbytes = nat.lib().msocr_conv3x3_winograd_workspace_bytes(ctypes.byref(d))
         if nbytes < 0:
             raise nat.NativeError(f"winograd: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-        rc = nat.lib().msocr_conv3x3_winograd(ctypes.byref(d), x.data_ptr(), u.data_ptr(), bp, rp, out.data_ptr(), ws.data_ptr(),
-                                              _stream())
-        nat.check(rc, f"msocr_conv3x3_winograd {tuple(x.shape)} * {tuple(w.shape)}")
+        parts = min(N, -(-nbytes // WINO_WS_LIMIT))  # images per call such that the workspace stays under the limit
+        per = -(-N // parts)
+        ws = _wino_workspace(nbytes if parts == 1 else (nbytes // N) * per, x.device)
+        what = f"msocr_conv3x3_winograd {tuple(x.shape)} * {tuple(w.shape)}"
+        for n0 in range(0, N, per):
+            n1 = min(N, n0 + per)
+            d.N = n1 - n0
+            xp, rp_, op = x[n0:n1].data_ptr(), (residual[n0:n1].data_ptr() if residual is not None else None), out[n0:n1].data_ptr()
+            if prof is None:
+                nat.check(nat.lib().msocr_conv3x3_winograd(ctypes.byref(d), xp, u.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
+            else:  # the same three kernels through the per-stage entry points, one event pair each
+                nn, mt = n1 - n0, (n1 - n0) * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+                e = _prof_begin()
+                nat.check(nat.lib().msocr_winograd_input_transform(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
+                _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + 16 * mt * Cin), (mt, Cin))
+                e = _prof_begin()
+                nat.check(nat.lib().msocr_winograd_gemm(ctypes.byref(d), u.data_ptr(), ws.data_ptr(), _stream()), what)
+                _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 16 * mt * Cin * Cout), (nn * Ho * Wo, Cout, KH * KW * Cin, "winograd"))
+                e = _prof_begin()
+                nat.check(nat.lib().msocr_winograd_output_transform(ctypes.byref(d), ws.data_ptr(), bp, rp_, op, _stream()), what)
+                _prof_end(e, "wino_out", 4.0 * (16 * mt * Cout + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))
+        d.N = N
     else:
+        e = _prof_begin()
         rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
         nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
-    if prof is not None:  # FLOPs are ALGORITHMIC (direct-convolution 2*MACs) for both paths; tag[4] = FLOPs the MFMAs execute
-        e1.record()
-        executed = 2.0 * 16 * N * ((Ho + 1) // 2) * ((Wo + 1) // 2) * Cin * Cout if use_wino else 2.0 * N * Ho * Wo * Cout * KH * KW * Cin
-        prof.append((e0, e1, 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin),
-                     (N * Ho * Wo, Cout, KH * KW * Cin, "winograd" if use_wino else "direct", executed)))
+        _prof_end(e, "conv_gemm", (alg, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin), (N * Ho * Wo, Cout, KH * KW * Cin, "direct"))
     return out
 
 
@@ -146,8 +201,10 @@ def maxpool2d(x, k, s, p, out=None):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    e = _prof_begin()
     nat.check(nat.lib().msocr_maxpool2d(x.data_ptr(), N, H, W, C, _pixel_dense_ld(x), k, s, p, _dt(x), out.data_ptr(), Ho, Wo,
                                         _pixel_dense_ld(out), _stream()), "maxpool2d")
+    _prof_end(e, "maxpool", float(x.element_size()) * N * C * (H * W + Ho * Wo))
     return out
 
 
@@ -201,10 +258,10 @@ def east_lanms(cand, counts, iou_thr, workspace=None):
 
 def east_box_tail(boxes, nbox, expand_w, expand_h, scale_x, scale_y, axis_aligned, remove_anomalies, sigma, min_count):
     """boxes [N,max_cand,9] f32 + nbox [N] i32 (device, from east_lanms) -> (final boxes [N,max_cand,9], counts [N] i32; -1 = page
-    with more than 2048 boxes, to be finished by the host path).  expand / scale / contained / anomalies / axis-aligned."""
+    with more than min(max_cand, 16384) boxes, to be finished by the host path).  expand / scale / contained / anomalies / axis-aligned."""
     _need_cuda(boxes, nbox)
     N, max_cand, _ = boxes.shape
-    ws = torch.empty((nat.lib().msocr_east_box_tail_workspace_bytes(N),), dtype=torch.uint8, device=boxes.device)
+    ws = torch.empty((nat.lib().msocr_east_box_tail_workspace_bytes(N, max_cand),), dtype=torch.uint8, device=boxes.device)
     out = torch.empty_like(boxes)
     n_out = torch.empty((N,), dtype=torch.int32, device=boxes.device)
     nat.check(nat.lib().msocr_east_box_tail(boxes.data_ptr(), nbox.data_ptr(), N, max_cand, float(expand_w), float(expand_h),
@@ -244,8 +301,10 @@ def se_residual(x, identity, w1, w2, out=None):
     if out is None:
         out = torch.empty_like(x)
     gate = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    e = _prof_begin()
     nat.check(nat.lib().msocr_se_residual(x.data_ptr(), identity.data_ptr(), N, H * W, C, _dt(x), w1.data_ptr(), w2.data_ptr(),
                                           gate.data_ptr(), out.data_ptr(), _stream()), "se_residual")
+    _prof_end(e, "se_residual", 3.0 * x.element_size() * N * H * W * C, (N, H * W, C))  # x + identity in, out (x re-read from cache)
     return out
 
 
@@ -264,7 +323,10 @@ def bilstm_recurrent(xproj, whh_t, B, T, H):
     _need_cuda(xproj, whh_t)
     assert xproj.is_contiguous() and xproj.numel() == B * T * 8 * H and whh_t.shape == (2, H, H, 4) and whh_t.is_contiguous()
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=xproj.device)
+    e = _prof_begin()
     nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
+    # per step per direction W_hh (4H x H f32) + B * (h + c + 4H pre-gates) * 4 B * 2
+    _prof_end(e, "bilstm", (2.0 * T * (4.0 * H * H * 4 + B * (H + H + 4 * H) * 4 * 2), T), (B, T, H))
     return out
 
 

@@ -185,12 +185,18 @@ class TrbaNet:
                                                    dtype=torch.float32).to(self.device)
                 torch.cuda.synchronize()
             lp = self._lp_cache[key]
+        e = ops._prof_begin()
         nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
                                             beam_size, lp.data_ptr() if lp is not None else None, float(temperature), sos_id, eos_id,
                                             -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(),
                                             chunks[0].data_ptr() if chunks else None, chunks[1].data_ptr() if chunks else None,
                                             chunks[2].data_ptr() if chunks else None, ops._stream()),
                   "attn_beam")
+        # SURVEY.md 8d, per decode step: proj_H + batch_H (shared by the beams) + LSTMCell W_ih (ctx part + one-hot rows), W_hh,
+        # generator, h2h + per row (h, c state + logits); the launch runs up to `steps` of them (chunk-level early exit)
+        V, R = self.V, B * beam_size
+        per_step = 4.0 * (2 * B * T * H + 4 * H * (H + V) + 4 * H * H + H * V + H * H + R * (4 * H + V))
+        ops._prof_end(e, "attn_beam", (per_step, steps), (B, T, beam_size))
         return ws, fin, lp
 
     def beam_finalize(self, ws, B, steps, beam_size, trun_dev):

@@ -141,8 +141,10 @@ class Attention(nn.Module):
         return logits
 
     @torch.no_grad()
-    def greedy(self, batch_H, max_len=25):
-        """model.py:227-259. Returns (logits B x T_run x V, ids B x T_run)."""
+    def greedy(self, batch_H, max_len=25, diag=None):
+        """model.py:227-259. Returns (logits B x T_run x V, ids B x T_run).
+        diag (checker only, no effect on the arithmetic): dict that receives "top2_margin" [B, T_run] = gap between the
+        largest and second largest logit of every step, i.e. the margin of every arg-max decision of this decode."""
         B = batch_H.size(0)
         hid = (torch.zeros(B, self.hidden_size), torch.zeros(B, self.hidden_size))
         tok = torch.full((B,), self.sos_id, dtype=torch.long)
@@ -155,12 +157,18 @@ class Attention(nn.Module):
             ids_all.append(tok)
             if bool((tok == self.eos_id).all()):  # stops only if EVERY row emits EOS at this step
                 break
+        if diag is not None:
+            t2 = torch.stack(logits_all, 1).topk(2, dim=-1).values
+            diag["top2_margin"] = (t2[..., 0] - t2[..., 1]).numpy()
         return torch.stack(logits_all, 1), torch.stack(ids_all, 1)
 
     @torch.no_grad()
-    def beam(self, batch_H, max_len=25, beam_size=5, alpha=0.9, temperature=1.7):
+    def beam(self, batch_H, max_len=25, beam_size=5, alpha=0.9, temperature=1.7, diag=None):
         """model.py:92-225. Returns (temperature-scaled logits of the best beam's
-        path B x T_run x V, tokens B x T_run without SOS)."""
+        path B x T_run x V, tokens B x T_run without SOS).
+        diag (checker only, no effect on the arithmetic): dict that receives the margins of every decision this search
+        takes — "boundary_gap" [B, T_run]: K-th minus (K+1)-th candidate of each step's top-k (what decides which
+        hypotheses survive), "beam_scores" [B, K] / "beam_tokens" [B, K, T_run]: the final hypotheses the arg-max picks from."""
         B, K, H, V = batch_H.size(0), beam_size, self.hidden_size, self.num_classes
         toks = torch.full((B, K, 1), self.sos_id, dtype=torch.long)
         score = torch.full((B, K), float("-inf"))
@@ -188,6 +196,9 @@ class Attention(nn.Module):
             else:
                 cand = total
             top, idx = torch.topk(cand.view(B, -1), k=K, dim=-1)
+            if diag is not None:
+                tk1 = torch.topk(cand.view(B, -1), k=K + 1, dim=-1).values
+                diag.setdefault("boundary_gap", []).append((tk1[:, K - 1] - tk1[:, K]).numpy())
             src = idx // V
             nxt = (idx % V).clamp(0, V - 1)
             gat = lambda x: x.gather(1, src.unsqueeze(-1).expand(-1, -1, x.size(-1)))
@@ -205,6 +216,10 @@ class Attention(nn.Module):
                 break
         best = score.argmax(-1)
         ar = torch.arange(B)
+        if diag is not None:
+            import numpy as np
+            diag["boundary_gap"] = np.stack(diag["boundary_gap"], 1)
+            diag["beam_scores"], diag["beam_tokens"] = score.numpy().copy(), toks[:, :, 1:].numpy().copy()
         return trace[ar, best], toks[ar, best][:, 1:]
 
 
@@ -227,12 +242,12 @@ class TRBANet(nn.Module):
     def encode(self, x):
         return self.enc_rnn(self.cnn_features(x))
 
-    def forward(self, x, max_len=25, mode="greedy", beam_size=5, alpha=0.6, temperature=1.0):
+    def forward(self, x, max_len=25, mode="greedy", beam_size=5, alpha=0.6, temperature=1.0, diag=None):
         enc = self.encode(x)
         if mode == "greedy":
-            return self.attn.greedy(enc, max_len)
+            return self.attn.greedy(enc, max_len, diag)
         if mode == "beam":
-            return self.attn.beam(enc, max_len, beam_size, alpha, temperature)
+            return self.attn.beam(enc, max_len, beam_size, alpha, temperature, diag)
         raise ValueError(f"Unknown decode mode: {mode}")
 
 

@@ -41,3 +41,7 @@ def compare_texts(got_texts, exp, itos, eos_id=2, max_ties=1):
         ties.append(i)
     assert len(ties) <= max_ties, (ties, [(got_texts[i], exp[i]["text"]) for i in ties])
     return same
+
+
+# all-random-weights decode parity: the checker lives with the oracle (bench.py's cpu_baseline uses it too)
+from oracle.decode_check import compare_decodes, oracle_decode_chunks  # noqa: E402,F401

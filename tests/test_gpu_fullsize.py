@@ -68,3 +68,135 @@ def test_trba_batch256_beam_text(gpu):
     same = compare_texts([r["text"] for r in got], exp, itos, max_ties=2)
     np.testing.assert_allclose([got[i]["confidence"] for i in same], [exp[i]["confidence"] for i in same], atol=1e-4)
     assert len(set(texts_e)) >= 20
+
+
+def _boxes_of(page):
+    return np.array([[c for pt in w.polygon for c in pt] + [w.detection_confidence] for w in page.blocks[0].words], dtype=np.float32).reshape(-1, 9)
+
+
+def test_east_batch8_full_resolution(gpu):
+    """configs[1] as stated: batch = 8 pages @ 2048x1536 in ONE launch sequence.  Pages 0 and 7 against the oracle's CPU network
+    (score 1e-4 abs, geometry 1e-3 of its max); every page of the batch bit-identical to the same page run alone (batching
+    changes the GEMM M only: same tiles, same summation order)."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.detectors._east.net import EastNet
+    from oracle import east_model as oem
+    from oracle import imgproc
+    H, W = 1536, 2048
+    sd = synth.east_state_dict(seed=20260128)
+    pages = np.stack([synth.synth_page(100 + i, H, W)[0] for i in range(8)])
+    net = EastNet(sd, torch.float32)
+    score, geo = net.forward(torch.from_numpy(pages).cuda())
+    s_all, g_all = score.cpu().numpy(), geo.cpu().numpy()
+    ref = oem.EASTNet()
+    ref.load_state_dict(sd)
+    ref.eval()
+    for i in (0, 7):
+        with torch.no_grad():
+            r = ref(torch.from_numpy(imgproc.east_preprocess(pages[i], W, H)))
+        rs, rg = r["score"][0, 0].numpy(), r["geometry"][0].permute(1, 2, 0).numpy()
+        assert np.abs(s_all[i] - rs).max() < 1e-4, i
+        assert np.abs(g_all[i] - rg).max() < 1e-3 * np.abs(rg).max(), i
+    for i in range(8):
+        s1, g1 = net.forward(torch.from_numpy(pages[i:i + 1]).cuda())
+        assert np.array_equal(s1[0].cpu().numpy(), s_all[i]) and np.array_equal(g1[0].cpu().numpy(), g_all[i]), i
+    assert len({s_all[i].tobytes() for i in range(8)}) == 8
+
+
+def test_config4_share_3072x4096_pipeline(gpu):
+    """BASELINE configs[4], one GPU's geometry: pages @ 4096x3072 with the native 3072x4096 network input (768x1024 maps,
+    injected).  Two pages through Pipeline.predict_batch; page 0 (2066 words: above the 2048 boxes the box filters used to
+    hold in LDS; 57 k candidates) against the oracle end to end — boxes bit-exact, reading order, texts under the near-tie
+    rule, confidences 1e-4; page 1 against the oracle's detector post-processing + reading order (bit-exact) with every word
+    recognised.  Peak reserved device memory is asserted (Winograd workspaces come from one arena per stream)."""
+    from conftest import compare_texts
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import east_post as P
+    from oracle import lanms as L
+    from oracle import pipeline_glue as G
+    from oracle import trba_model as otm
+    from test_gpu_pipeline import _oracle_pipeline
+    H, W = 3072, 4096
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    tsd = synth.trba_state_dict_confident(194, 256, seed=20260128)
+    det = EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda")
+    rec = TRBA(state_dict=tsd, config=cfg, device="cuda")
+    assert det._max_candidates() == 384 * 512
+    pipe = Pipeline(detector=det, recognizer=rec)
+    pages, maps = [], []
+    for seed in (1000, 1001):
+        pg, rects = synth.synth_page(seed, H, W)
+        pages.append(pg)
+        maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+    mo = (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    got = pipe.predict_batch(pages, _maps_override=mo)
+    torch.cuda.synchronize()
+    peak_gb = torch.cuda.max_memory_reserved() / 2 ** 30
+    print(f"configs[4] share, 2 pages: peak reserved {peak_gb:.1f} GiB, words {[len(p.blocks[0].words) for p in got]}")
+    assert peak_gb < 48, peak_gb
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(tsd)
+    ref_net.eval()
+    itos, _ = otm.load_charset(CHARSET)
+    # page 0: the whole reference path on the CPU
+    exp = _oracle_pipeline(pages[0], maps[0][0], maps[0][1], ref_net, itos, cfg)
+    gw = got[0].blocks[0].words
+    assert len(gw) == len(exp) and len(exp) > 2048
+    n_text = ties = 0
+    for a, b in zip(gw, exp):
+        assert [tuple(p) for p in a.polygon] == [tuple(p) for p in b["polygon"]]
+        assert a.detection_confidence == b["det"]
+        if b["rec"] is None:
+            assert a.text is None and a.recognition_confidence is None
+        elif a.text != b["text"]:
+            ties += len(compare_texts([a.text], [b], itos)) == 0
+        else:
+            assert abs(a.recognition_confidence - b["rec"]) < 1e-4
+            n_text += 1
+    assert n_text > 2000 and ties <= 2, (n_text, ties)
+    # page 1: detector post-processing and reading order against the oracle, bit for bit
+    quads = P.east_postprocess(maps[1][0], maps[1][1], (H, W), (W, H), L.locality_aware_nms)
+    polys = [q[:8].reshape(4, 2).tolist() for q in quads]
+    order, kept, crops = G.order_and_crop(polys, pages[1], 5)
+    gw1 = got[1].blocks[0].words
+    assert len(gw1) == len(order) > 1500
+    assert [[tuple(p) for p in w.polygon] for w in gw1] == [[tuple(p) for p in polys[wi]] for wi in order]
+    assert [w.detection_confidence for w in gw1] == [float(quads[wi][8]) for wi in order]
+    assert sum(w.text is not None for w in gw1) == len(kept)
+
+
+def test_east_dense_page_above_old_capacities(gpu):
+    """Detector post-processing at the configs[4] map size on pages that exceed the round-1 capacities: (a) > 65536 candidate
+    cells (one third of the 768x1024 map above threshold), (b) > 2048 boxes after the NMS, through the device box filters
+    (per-box arrays in the workspace instead of LDS), (c) the same page through the HOST fallback tail: all bit-identical
+    to the oracle (decode -> LANMS -> expand -> scale -> contained -> anomalies -> axis-aligned)."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.detectors import EAST
+    from oracle import east_post as P
+    from oracle import lanms as L
+    H, W = 3072, 4096
+    det = EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda")
+    # (a) long, tall words: 0.35 of the cells above threshold
+    rects = np.array([(60 + 2000 * c, 40 + 126 * r, 60 + 2000 * c + 1900, 40 + 126 * r + 120) for r in range(23) for c in range(2)], dtype=np.float64)
+    dense = synth.synth_maps(rects, (H, W), (H // 4, W // 4), 5)
+    # (b) a tight layout: ~2460 words
+    page_b, rects_b = synth.synth_page(1000, H, W, line_pitch=30, word_h=24)
+    many = synth.synth_maps(rects_b, (H, W), (H // 4, W // 4), 6)
+    page = np.zeros((H, W, 3), dtype=np.uint8)
+    mo = (torch.from_numpy(np.stack([dense[0], many[0]])).cuda(), torch.from_numpy(np.stack([dense[1], many[1]])).cuda())
+    res = det.predict_batch([page, page], _maps_override=mo)
+    n_cand = [len(P.decode_quads_from_maps(m[0], m[1], 0.6, 4.0, 2)) for m in (dense, many)]
+    assert n_cand[0] > 65536, n_cand
+    exp = [P.east_postprocess(m[0], m[1], (H, W), (W, H), L.locality_aware_nms) for m in (dense, many)]
+    assert len(exp[1]) > 2048, len(exp[1])
+    for r, e in zip(res, exp):
+        got = _boxes_of(r["page"])
+        assert got.shape == e.shape and np.array_equal(got, e), (got.shape, e.shape)
+    det.device_tail = False  # (c) host fallback tail (what a page above 16384 boxes takes)
+    res_h = det.predict_batch([page, page], _maps_override=mo)
+    for r, e in zip(res_h, exp):
+        assert np.array_equal(_boxes_of(r["page"]), e)

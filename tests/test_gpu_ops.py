@@ -374,11 +374,11 @@ def _random_quads(rng, M, trial):
     return q
 
 
-def test_east_box_tail_device_equals_numpy_host_tail(ops):
+def test_east_box_tail_device_equals_oracle_tail(ops):
     """msocr_east_box_tail (expand, scale, contained-box removal, area anomalies, axis-aligned; one workgroup per page) against the
-    NumPy host tail of detectors/_east/post.py: bit-identical boxes, page by page, over random layouts with nested / giant /
-    reversed / integer-coordinate quads and all parameter combinations; pages with more than 2048 boxes are flagged (-1)."""
-    from manuscript_ocr_amd.detectors._east import post
+    ORACLE's restatement of infer.py:134-233 / utils.py:384-422 (oracle/east_post.py): bit-identical boxes, page by page, over
+    random layouts with nested / giant / reversed / integer-coordinate quads and all parameter combinations."""
+    from oracle import east_post as P
     rng = np.random.default_rng(5)
     for trial in range(24):
         counts = [int(c) for c in rng.choice([0, 1, 2, 5, 31, 32, 60, 200, 500, 1500], size=3)]
@@ -397,13 +397,19 @@ def test_east_box_tail_device_equals_numpy_host_tail(ops):
                                        ohw[1] / twh[0], ohw[0] / twh[1], kw["aa"], kw["anom"], 5.0, kw["minc"])
         out, n_out = out.cpu().numpy(), n_out.cpu().numpy()
         for pg, q in enumerate(quads):
-            e = post.expand_boxes(q.copy(), kw["ew"], kw["eh"])
-            e = post.scale_boxes(e, ohw, twh)
-            e = post.remove_contained(e)
-            e = post.remove_area_anomalies(e, kw["anom"], 5.0, kw["minc"])
-            e = post.to_axis_aligned(e) if kw["aa"] else e
+            e = P.expand_boxes(q.copy(), kw["ew"], kw["eh"])
+            e = P.scale_boxes_to_original(e, ohw, twh)
+            e = P.remove_fully_contained_boxes(e)
+            e = P.remove_area_anomalies(e, kw["anom"], 5.0, kw["minc"])
+            e = P.convert_to_axis_aligned(e) if kw["aa"] else e
             assert n_out[pg] == len(e), (trial, pg, counts[pg], n_out[pg], len(e))
             assert np.array_equal(out[pg, : len(e)], e), (trial, pg)
-    big = torch.zeros((1, 2304, 9), dtype=torch.float32).cuda()
-    _, n_big = ops.east_box_tail(big, torch.tensor([2100], dtype=torch.int32).cuda(), 0.9, 0.9, 1.0, 1.0, True, True, 5.0, 30)
-    assert int(n_big[0]) == -1
+    # a page above the 2048 boxes whose per-box arrays fit LDS (they move to the workspace), and a count above the capacity (-1)
+    q = _random_quads(rng, 2300, 1)
+    big = np.zeros((2, 2304, 9), dtype=np.float32)
+    big[0, :2300] = q
+    out, n_big = ops.east_box_tail(torch.from_numpy(big).cuda(), torch.tensor([2300, 2400], dtype=torch.int32).cuda(), 0.9, 0.9, 1.5, 1.25,
+                                   True, True, 5.0, 30)
+    e = P.convert_to_axis_aligned(P.remove_area_anomalies(P.remove_fully_contained_boxes(P.scale_boxes_to_original(
+        P.expand_boxes(q.copy(), 0.9, 0.9), (1250, 1500), (1000, 1000))), True, 5.0, 30))
+    assert int(n_big[1]) == -1 and int(n_big[0]) == len(e) and np.array_equal(out[0, :len(e)].cpu().numpy(), e)

@@ -140,6 +140,135 @@ def test_trba_predict_matches_oracle_text_and_confidence(env, mode):
     np.testing.assert_allclose([got[i]["confidence"] for i in same], [exp[i]["confidence"] for i in same], atol=1e-4)
 
 
+def _random_weight_case(otm, seed, N, mode, rec):
+    """GPU decode (ids, run lengths, logits, confidences) and the oracle's rows for N synthetic crops, all-random weights."""
+    from conftest import oracle_decode_chunks
+    sd = synth.trba_state_dict(194, 256, seed=seed)
+    canv = synth.synth_crops(seed % 1000 + 5, N, 32, 100)
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(sd, strict=True)
+    ref_net.eval()
+    exp = oracle_decode_chunks(ref_net, _x_from_canvases(canv), mode)
+    ids, trun, conf, lg = rec.recognize_canvases(torch.from_numpy(canv).cuda(), batch_size=32, mode=mode, return_logits=True)
+    return ids, trun, conf, lg, exp
+
+
+def _assert_near_tie_parity(rep, N, what):
+    """Zero differences that are not near-ties of the oracle's own decode; near-tie rows capped at 3 % (+1)."""
+    msg = (f"{what}: {len(rep['same'])}/{N} rows identical, ties {rep['ties']}, run-length-only rows {rep['run_length_only']}, "
+           f"hard {rep['hard']}, max logit err {rep['max_logit_err_rel']:.2e} of max|logit|")
+    print(msg)
+    assert not rep["hard"], msg
+    assert len(rep["ties"]) <= 1 + (3 * N) // 100, msg
+    p90 = float(np.quantile(rep["row_logit_err_rel"], 0.9))
+    print(f"{what}: logit error / max|logit| per row: median {np.median(rep['row_logit_err_rel']):.2e}, p90 {p90:.2e}")
+    assert p90 < RANDOM_LOGIT_P90, (what, p90)
+
+
+RANDOM_WEIGHT_SEED = 20260128
+RANDOM_LOGIT_RTOL = 3e-2
+RANDOM_LOGIT_P90 = 1e-3
+
+
+@pytest.mark.parametrize("mode", ["greedy", "beam"])
+def test_trba_random_weights_decode_parity(env, mode):
+    """ALL-RANDOM weights (synth.trba_state_dict: x6 recurrent gain, every character an arg-max over near-Gaussian logits —
+    the most rounding-sensitive decoder we can build), 256 crops, the reference's 32-row chunks.  Every row must reproduce
+    the oracle's ids at every generated step; the only admitted difference is at the FIRST differing step and only where the
+    oracle's own decision margin there is below TIE_TOL (conftest.compare_decodes).  Logits up to that step: this decoder is
+    chaotic (x6 recurrent gain, 25-26 chained steps) — the CPU oracle against ITSELF under a 1e-7 input perturbation moves
+    by 2e-5..9e-5 of the largest |logit| on 90 % of the rows and by up to 8e-3 on the worst ones
+    (tests/test_oracle_trba.py::test_oracle_self_sensitivity) — so the bound is on the distribution: 90 % of the rows within
+    RANDOM_LOGIT_P90 = 1e-3, every row within RANDOM_LOGIT_RTOL = 3e-2 (the 6 golden crops of
+    test_trba_vs_reference_goldens hold 1e-3).  Confidences of identical rows within 2e-3 on 90 % of them and 3e-2 on all (a mean
+    of softmax probabilities whose logits carry that error; the planted-decoder test above holds 1e-4)."""
+    from conftest import compare_decodes
+    from manuscript_ocr_amd.recognizers import TRBA
+    otm = env
+    N = 256
+    rec = TRBA(state_dict=synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED),
+               config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda")
+    ids, trun, conf, lg, exp = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, mode, rec)
+    rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=RANDOM_LOGIT_RTOL)
+    _assert_near_tie_parity(rep, N, f"random weights / {mode}")
+    assert len({tuple(e["ids"].tolist()) for e in exp}) > N // 2, "degenerate fixture: decodes do not vary"
+    itos, _ = otm.load_charset(CHARSET)
+    by_chunk = {}
+    for i, e in enumerate(exp):
+        by_chunk.setdefault(e["chunk"], []).append(i)
+    for ch, rows in by_chunk.items():  # confidences depend on the chunk's run length: compare chunks without a tie row
+        if ch in rep["chunks_with_ties"]:
+            continue
+        lg_c = torch.from_numpy(np.stack([exp[i]["logits"] for i in rows]))
+        ids_c = torch.from_numpy(np.stack([exp[i]["ids"] for i in rows]))
+        ref = otm.texts_and_confidences(lg_c, ids_c, itos, 0, 2, None)
+        got_texts = rec.texts(ids[rows], trun[rows])
+        assert got_texts == [r["text"] for r in ref]
+        dconf = np.abs(conf[rows] - np.array([r["confidence"] for r in ref]))
+        assert np.quantile(dconf, 0.9) < 2e-3 and dconf.max() < 3e-2, (ch, dconf.max())
+
+
+@pytest.mark.parametrize("mode", ["greedy", "beam"])
+def test_trba_random_weights_recorded_round1_case(env, mode):
+    """The input that was red in round 1 (gpurun_out/s2_tests.log: 40 resized crops of synth_crops(77), all-random weights,
+    texts compared by equality; crop 29 diverged at character 21) under the first-differing-step rule: every differing row
+    must be a near-tie of the oracle's own decode, and its margin is printed for the record."""
+    from conftest import compare_decodes, oracle_decode_chunks
+    from manuscript_ocr_amd.recognizers import TRBA
+    from oracle import imgproc
+    otm = env
+    sd = synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED)
+    rec = TRBA(state_dict=sd, config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda")
+    rng = np.random.default_rng(3)
+    crops = []
+    for c in synth.synth_crops(77, 40, 32, 100):
+        hh, ww = int(rng.integers(20, 60)), int(rng.integers(40, 220))
+        crops.append(imgproc.resize_linear_u8(c, ww, hh))
+    canv = np.stack([imgproc.resize_and_pad(c, 32, 100) for c in crops])
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(sd, strict=True)
+    ref_net.eval()
+    exp = oracle_decode_chunks(ref_net, _x_from_canvases(canv), mode)
+    ids, trun, conf, lg = rec.recognize_canvases(torch.from_numpy(canv).cuda(), batch_size=32, mode=mode, return_logits=True)
+    rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=RANDOM_LOGIT_RTOL)
+    _assert_near_tie_parity(rep, 40, f"round-1 recorded case / {mode}")
+
+
+def test_trba_random_weights_three_way(env, monkeypatch):
+    """The same 256 all-random-weight crops through (a) the default path (Winograd 3x3 layers, matrix-core beam kernel),
+    (b) direct convolutions only (MSOCR_WINOGRAD_MIN_CIN=0), (c) the VALU beam kernel (MSOCR_BEAM_MFMA=0): each against the
+    oracle under the near-tie rule, and pairwise: rows that are identical to the oracle in two variants are identical to
+    each other, so the variants can only differ on the oracle's near-tie rows."""
+    from conftest import compare_decodes
+    from manuscript_ocr_amd import ops
+    from manuscript_ocr_amd.recognizers import TRBA
+    otm = env
+    N, cfg = 256, {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    sd = synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED)
+    results = {}
+    rec_w = TRBA(state_dict=sd, config=cfg, device="cuda")
+    results["winograd+mfma-beam"] = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, "beam", rec_w)
+    monkeypatch.setenv("MSOCR_BEAM_MFMA", "0")
+    results["winograd+valu-beam"] = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, "beam", rec_w)
+    monkeypatch.delenv("MSOCR_BEAM_MFMA")
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_CIN", 0)
+    rec_d = TRBA(state_dict=sd, config=cfg, device="cuda")
+    assert not any(hasattr(w, "_msocr_wino") for w, _ in rec_d.model.P.values())
+    results["direct+mfma-beam"] = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, "beam", rec_d)
+    same = {}
+    for name, (ids, trun, conf, lg, exp) in results.items():
+        rep = compare_decodes(ids, trun, lg, exp, "beam", logit_rtol=RANDOM_LOGIT_RTOL)
+        _assert_near_tie_parity(rep, N, name)
+        same[name] = set(rep["same"])
+    names = list(results)
+    for a in names:
+        for b in names:
+            if a < b:
+                for i in same[a] & same[b]:
+                    ta = int(results[a][1][i])
+                    assert ta == int(results[b][1][i]) and np.array_equal(results[a][0][i][:ta], results[b][0][i][:ta]), (a, b, i)
+
+
 def test_trba_bf16_cnn_close(env):
     """bf16 CNN (f32 accumulate; recurrent/attention stay f32).  Stated tolerance: CNN features within
     3 % of their max; the encoder output, which the x6-scaled synthetic LSTM weights amplify, within 15 %."""

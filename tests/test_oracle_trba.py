@@ -43,3 +43,29 @@ def test_charset_and_decode_tokens():
     assert len(itos) == 194 and itos[:4] == ["<PAD>", "<SOS>", "<EOS>", " "] and "<BLANK>" not in stoi
     assert otm.decode_tokens([4, 0, 5, 2, 6], itos, 0, 2, None) == "ab"
     assert otm.decode_tokens([], itos, 0, 2, None) == ""
+
+
+def test_oracle_self_sensitivity():
+    """How chaotic the all-random-weights decoder is, measured on the CPU oracle alone: a 1e-7 (rounding-level) perturbation
+    of the input (1e-5 at the encoder output) moves its own logits by 2e-5..9e-5 of the largest |logit| on 90 % of the rows
+    and by up to ~3e-2 on the worst row over the 25-26 chained steps; where its ids change, they change at a near-tie of its
+    own decode (conftest.compare_decodes).  This is the yardstick for the tolerances of
+    tests/test_gpu_trba.py::test_trba_random_weights_*."""
+    from conftest import compare_decodes, oracle_decode_chunks
+    N = 64
+    net = _net(20260128)
+    crops = synth.synth_crops(77, N, 32, 100)
+    x = torch.from_numpy(((crops.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
+    xp = x + 1e-7 * torch.randn(x.shape, generator=torch.Generator().manual_seed(1))
+    for mode, steps in (("greedy", 26), ("beam", 25)):
+        a, b = oracle_decode_chunks(net, x, mode), oracle_decode_chunks(net, xp, mode)
+        ids = np.full((N, steps), -1, np.int64)
+        lg = np.zeros((N, steps, 194), np.float32)
+        trun = np.zeros(N, np.int32)
+        for i, r in enumerate(b):
+            T = len(r["ids"])
+            ids[i, :T], lg[i, :T], trun[i] = r["ids"], r["logits"], T
+        rep = compare_decodes(ids, trun, lg, a, mode, logit_rtol=5e-2)
+        assert not rep["hard"], (mode, rep["hard"])
+        assert len(rep["ties"]) <= 3, (mode, rep["ties"])
+        assert 1e-5 < np.quantile(rep["row_logit_err_rel"], 0.9) < 3e-4, (mode, np.quantile(rep["row_logit_err_rel"], 0.9))
