@@ -453,8 +453,8 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     el = time.perf_counter() - t0
     extra = {}
     if workload == "pipeline" and sample_crops:
-        extra["random_weight_decoder"] = random_weight_leg(sample_crops[:256], itos)
-    extra["real_network_chain"] = real_network_leg(esd, net, pages[0])
+        extra["random_weight_decoder"] = cpu_baseline_random_weight_leg(sample_crops[:256], itos)
+    extra["real_network_chain"] = cpu_baseline_real_network_leg(esd, net, pages[0])
     return {
         **extra,
         "value": n / el,
@@ -471,7 +471,7 @@ def cpu_baseline(workload, esd, tsd, pages, scores, geos, H, W, gpu_pages, budge
     }
 
 
-def random_weight_leg(crops, itos):
+def cpu_baseline_random_weight_leg(crops, itos):
     """Text parity where it is hardest: the same word crops through an ALL-RANDOM-weights recogniser (every character an arg-max
     over near-Gaussian logits, x6 recurrent gain) on the device and in the CPU oracle, beam-8, compared row by row with the
     first-differing-step near-tie rule (oracle/decode_check.py).  Outside the timed region and outside cpu_baseline.value."""
@@ -501,7 +501,7 @@ def random_weight_leg(crops, itos):
             "logit_err_rel_p90": float(np.quantile(rep["row_logit_err_rel"], 0.9)), "logit_err_rel_max": rep["max_logit_err_rel"]}
 
 
-def real_network_leg(esd, oracle_net, page, hw=(256, 384)):
+def cpu_baseline_real_network_leg(esd, oracle_net, page, hw=(256, 384)):
     """EAST forward -> decode -> LANMS -> filters with the maps of the REAL network on both sides (no injection), on a small
     window of the page: device chain vs oracle chain.  Random weights give meaningless but deterministic boxes; the two
     chains see maps that differ by f32 rounding, so boxes are matched within a pixel tolerance, not bit for bit."""

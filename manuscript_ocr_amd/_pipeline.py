@@ -222,15 +222,25 @@ class Pipeline:
                 pool.append(torch.cuda.Stream())
                 dpool.append(torch.cuda.Stream(priority=hi_prio))
             streams, det_streams = pool[:nsub], dpool[:nsub]
-        det_handles = []
+        from . import ops
+        det_handles, ro_handles = [], []
+        H, W = arrays[0].shape[:2]
         for (lo, hi), st in zip(bounds, det_streams):
             if st is not main:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
                 mo = None if _maps_override is None else (_maps_override[0][lo:hi], _maps_override[1][lo:hi])
-                det_handles.append(det.detect_start(pages_dev[lo:hi], mo))
+                dh = det.detect_start(pages_dev[lo:hi], mo)
+                det_handles.append(dh)
+                # reading order + crop descriptors of the group's pages on the device, right behind the box filters: the host
+                # then needs only the crop COUNTS to enqueue the recogniser (Page / Word assembly moves to collect_batch)
+                ro = None
+                if recognize_text and dh[5] is not None and getattr(self, "device_order", True):
+                    ro = ops.reading_order_crops(dh[5], dh[6], (H, W), self.min_text_size, self.recognizer.img_h, self.recognizer.img_w,
+                                                 page_base=lo)
+                ro_handles.append(ro)
         return {"arrays": arrays, "pages_dev": pages_dev, "bounds": bounds, "streams": streams, "det_streams": det_streams, "main": main,
-                "det_handles": det_handles, "recognize_text": recognize_text, "profile": profile}
+                "det_handles": det_handles, "ro_handles": ro_handles, "recognize_text": recognize_text, "profile": profile}
 
     def advance_batch(self, h):
         """Stage 2 of `predict_batch` for a handle from `submit_batch`: per group — wait for its boxes, run the host
@@ -250,7 +260,35 @@ class Pipeline:
         H, W = arrays[0].shape[:2]
         pages, groups = [None] * N, []
         with _gc_paused():
-            for (lo, hi), st, dst, dh in zip(bounds, streams, h["det_streams"], h["det_handles"]):
+            for (lo, hi), st, dst, dh, ro in zip(bounds, streams, h["det_streams"], h["det_handles"], h["ro_handles"]):
+                if ro is not None:
+                    # device path: wait for the group's crop counts only (4 bytes per page), enqueue crops + recogniser
+                    with torch.cuda.stream(dst):
+                        t0 = time.perf_counter()
+                        nc_h = ro[3].cpu().numpy()
+                        tm["detect_wait+tail"] += time.perf_counter() - t0
+                    if bool((nc_h >= 0).all()):
+                        t0 = time.perf_counter()
+                        grp = {"words": None, "spans": [], "handle": None, "ro": ro, "det": dh, "lohi": (lo, hi), "dst": dst}
+                        off = 0
+                        for c in nc_h.tolist():
+                            grp["spans"].append([off, c])
+                            off += c
+                        if off:
+                            spans = [tuple(sp) for sp in grp["spans"] if sp[1] > 0]
+                            with torch.cuda.stream(dst):  # the small blocking upload rides the high-priority stream
+                                prepared = rec.prepare_chunks(off, spans)
+                            if st is not h["main"]:
+                                st.wait_stream(h["main"])  # the page upload
+                            st.wait_stream(dst)
+                            with torch.cuda.stream(st):
+                                ro[2].record_stream(st)
+                                desc_dev = torch.cat([ro[2][pi, :c] for pi, c in enumerate(nc_h.tolist()) if c])
+                                canv = ops.crop_resize_pad(pages_dev, None, rec.img_h, rec.img_w, desc_dev=desc_dev)
+                                grp["handle"] = rec.recognize_start(canv, spans=spans, prepared=prepared)
+                        tm["crop+enqueue"] += time.perf_counter() - t0
+                        groups.append(grp)
+                        continue
                 with torch.cuda.stream(dst):
                     t0 = time.perf_counter()
                     res = det.detect_finish(dh, arrays[lo:hi], profile=profile)
@@ -311,6 +349,28 @@ class Pipeline:
         pages, groups, tm = h["pages"], h["groups"], h["tm"]
         with _gc_paused():
             for grp, st in zip(groups, streams):
+                if grp.get("ro") is not None:
+                    # device-ordered group: Page / Word assembly happens here, off the path that feeds the device
+                    lo, hi = grp["lohi"]
+                    with torch.cuda.stream(grp["dst"]):
+                        t0 = time.perf_counter()
+                        res = self.detector.detect_finish(grp["det"], h["arrays"][lo:hi], profile=profile)
+                        order_h, keep_h = grp["ro"][0].cpu().numpy(), grp["ro"][1].cpu().numpy()
+                        tm["detect_wait+tail"] += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    grp["words"] = []
+                    for pi, r in enumerate(res):
+                        page = self._page_of(r)
+                        pages[lo + pi] = page
+                        k0 = 0
+                        for block in page.blocks:  # this package's EAST returns one block (infer.py:390)
+                            nw = len(block.words)
+                            if nw:
+                                old = block.words
+                                block.words = [old[k] for k in order_h[pi, k0:k0 + nw].tolist()]
+                                grp["words"] += [block.words[pos] for pos in np.flatnonzero(keep_h[pi, k0:k0 + nw]).tolist()]
+                            k0 += nw
+                    tm["order"] += time.perf_counter() - t0
                 if grp["handle"] is not None:
                     with torch.cuda.stream(st):
                         t0 = time.perf_counter()

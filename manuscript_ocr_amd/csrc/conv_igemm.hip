@@ -90,8 +90,11 @@ __device__ __forceinline__ int swz(int row) {
 // LEAN: 1x1 kernel without padding (every 1x1 convolution and the batched GEMMs of the Winograd path) — a K-tile is a plain
 // pointer increment, no tap decoding, no bounds masks (rows >= M load valid garbage that the epilogue never stores).  PMC on
 // the Winograd GEMM counted 1.9 VALU + 1.2 SALU instructions per MFMA in the general loader; they share the SIMD's issue port.
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32>
-__global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv_igemm_kernel(ConvParams p) {
+// WPE: workgroups per CU the register allocation is held to (0 = 3 for the one-stage 128-byte-row form, else 2); STAG: stagger
+// the start of every third workgroup of a CU's share by part of a K-tile so that co-resident workgroups do not run their
+// barrier / staging phases in lockstep (diagnostic variants, MSOCR_GEMM_VARIANT).
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0>
+__global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 : 2)) void conv_igemm_kernel(ConvParams p) {
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
   constexpr int EPC = 16 / ES;   // elements per chunk
@@ -223,6 +226,10 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
 
   const int r32 = lane & (MT - 1), half = lane / MT;
 
+  if constexpr (STAG != 0) {  // blocks b, b + 256, b + 512 tend to share a CU: delay them by 0 / 1 / 2 thirds of a K-tile's MFMA time
+    const int ph = (blockIdx.x >> 8) % 3;
+    for (int q = 0; q < ph * STAG; ++q) __builtin_amdgcn_s_sleep(127);
+  }
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 && BKB <= 128) ? 3 : 2) void conv
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -371,7 +378,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI = (BM / WM) * 32 * BN * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT>;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT, WPE, STAG>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -400,8 +407,15 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
       static const int mt16 = getenv("MSOCR_CONV_MT16") ? atoi(getenv("MSOCR_CONV_MT16")) : 1;
       if (wide && variant == 1 && mt16 == 2 && !(lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0))
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, false, 16>(p, s);
-      if (wide && variant == 1 && lean_on && mt16 && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
+      if (wide && variant == 1 && lean_on && mt16 && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0) {
+        const int gv = getenv("MSOCR_GEMM_VARIANT") ? atoi(getenv("MSOCR_GEMM_VARIANT")) : 0;  // diagnostics (tools/gemm_probe.py)
+        if (gv == 1 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1, true, 16, 2>(p, s);  // BK = 64, 2 per CU
+        if (gv == 2) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);                              // BK = 16, 4 per CU
+        if (gv == 3) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 3, 8>(p, s);                          // staggered start
+        if (gv == 4) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 4>(p, s);                             // 4 per CU (128 VGPRs)
+        if (gv == 5) return launch_cfg<T, 128, 128, 128, 64, 64, 2, true, 16, 2>(p, s);                             // two LDS stages, 2 per CU
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16>(p, s);
+      }
       if (wide && variant == 1 && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, true>(p, s);
     }

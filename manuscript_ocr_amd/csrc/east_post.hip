@@ -251,8 +251,17 @@ __device__ __forceinline__ bool key_less(K a, K b) { return a < b || (b != b && 
 //   order  i32[max_cand], supp i32[max_cand], flag i32[max_cand], sbreak i32[max_cand]
 #define LANMS_T 1024
 #define CARRY_W 11
+// phase 2 across the chip: pages with at most NMS_BITCAP merged polygons get their "IoU > thr" relation as a bit matrix
+// computed by many workgroups (lanms_iou_bits_kernel) and a single wave then replays the greedy pass on the bits
+#define NMS_BITCAP 8192
+#define NMS_BITW (NMS_BITCAP / 32)
+static inline int64_t lanms_bits_off(int max_cand) {
+  return ((int64_t)max_cand * (2 * (64 + 8) + 4 * 4) + (int64_t)3 * LANMS_T * CARRY_W * 8 + 64 + 63) / 64 * 64;
+}
+static inline int nms_bitcap(int max_cand) { return ((max_cand < NMS_BITCAP ? max_cand : NMS_BITCAP) + 31) / 32 * 32; }
 static inline int64_t lanms_ws_per_page(int max_cand) {
-  return (int64_t)max_cand * (2 * (64 + 8) + 4 * 4) + (int64_t)3 * LANMS_T * CARRY_W * 8 + 64;
+  const int64_t cap = nms_bitcap(max_cand);
+  return lanms_bits_off(max_cand) + cap * (cap / 32) * 4 + 64;  // ... + bit matrix [cap][cap/32] u32 + {nm} header
 }
 extern "C" int64_t msocr_lanms_workspace_bytes(int N, int max_cand) {
   if (N <= 0 || max_cand <= 0) return 0;
@@ -384,7 +393,8 @@ __device__ __forceinline__ bool merge_step(MergeState& st, const float* b, doubl
 
 __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
                                                               int max_cand, double thr, float* __restrict__ boxes_out,
-                                                              int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride, long long* dbg) {
+                                                              int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride, long long* dbg,
+                                                              long bits_off, int bitcap) {
   const int pg = blockIdx.x;
   const int tid = threadIdx.x, nthr = LANMS_T;
 #define DBG_STAMP(k) do { if (dbg && tid == 0) dbg[pg * 8 + (k)] = wall_clock64(); } while (0)
@@ -408,8 +418,9 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   __shared__ int scan_s[LANMS_T / 64];
   __shared__ unsigned char ch_s[LANMS_T];
 
+  int32_t* nm_hdr = reinterpret_cast<int32_t*>(w + bits_off);  // {merged polygons for the bit-matrix path, or -1}
   if (n == 0) {
-    if (tid == 0) nbox_out[pg] = 0;
+    if (tid == 0) { nbox_out[pg] = 0; nm_hdr[0] = -1; }
     return;
   }
   // ---- `order` already holds the stable argsort by x0 (lanms.py:166-168), computed by lanms_rank_x0_kernel
@@ -538,6 +549,13 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   DBG_STAMP(5);
   // ---- phase 2: order = argsort(-score) (stable), greedy suppression (lanms.py:133-153)
   block_rank_sort_neg_f64(nm, mscore, order, rs_tile);
+  if (bitcap > 0 && nm <= bitcap) {  // greedy suppression continues in lanms_iou_bits_kernel + lanms_greedy_bits_kernel
+    if (tid == 0) nm_hdr[0] = nm;
+    DBG_STAMP(6);
+    if (dbg && tid == 0) dbg[pg * 8 + 7] = ((long long)n << 32) | (unsigned)nm;
+    return;
+  }
+  if (tid == 0) nm_hdr[0] = -1;
   for (int i = tid; i < nm; i += nthr) supp[i] = 0;
   __syncthreads();
   int nk = 0;  // kept count (every thread tracks it; the owner of a kept polygon writes its row)
@@ -615,6 +633,73 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   if (dbg && tid == 0) dbg[pg * 8 + 7] = ((long long)n << 32) | (unsigned)nm;
 }
 
+// bit j of bits[i][w] (j = 32w + b > i, sorted positions): polygon_iou(poly_i, poly_j) > thr, the test of lanms.py:147-150 with
+// the same argument order.  grid (row blocks of 8, pages), 256 threads: thread = (row, word) pairs in a strided loop.
+__global__ __launch_bounds__(256) void lanms_iou_bits_kernel(char* __restrict__ ws, long ws_stride, int max_cand, double thr, long bits_off,
+                                                              int bitcap) {
+  const int pg = blockIdx.y;
+  char* w = ws + (long)pg * ws_stride;
+  const int nm = reinterpret_cast<const int32_t*>(w + bits_off)[0];
+  if (nm <= 0) return;
+  const int W = (nm + 31) >> 5, capw = bitcap >> 5;
+  const double* mpoly = reinterpret_cast<const double*>(w);
+  const int32_t* order = reinterpret_cast<const int32_t*>(w + ((long)max_cand * (2 * (64 + 8)) + (long)3 * LANMS_T * CARRY_W * 8));
+  uint32_t* bits = reinterpret_cast<uint32_t*>(w + bits_off + 64);
+  const long total = (long)nm * W;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx / W), wd = (int)(idx - (long)i * W);
+    uint32_t v = 0u;
+    if (32 * wd + 31 > i) {
+      double a[8];
+      const double* pa = mpoly + (long)order[i] * 8;
+      for (int k = 0; k < 8; ++k) a[k] = pa[k];
+      for (int b = 0; b < 32; ++b) {
+        const int j = 32 * wd + b;
+        if (j > i && j < nm && d_polygon_iou_q(a, mpoly + (long)order[j] * 8) > thr) v |= 1u << b;
+      }
+    }
+    bits[(long)i * capw + wd] = v;
+  }
+}
+
+// the greedy pass of standard_nms (lanms.py:141-152) on the bit matrix: one wave per page, lane l owns the suppression words
+// l, l + 64, ...; a kept polygon ORs its row into them.  Output rows in kept order, like the reference's `keep` list.
+__global__ __launch_bounds__(64) void lanms_greedy_bits_kernel(char* __restrict__ ws, long ws_stride, int max_cand, long bits_off, int bitcap,
+                                                                float* __restrict__ boxes_out, int32_t* __restrict__ nbox_out) {
+  const int pg = blockIdx.x, lane = threadIdx.x;
+  char* w = ws + (long)pg * ws_stride;
+  const int nm = reinterpret_cast<const int32_t*>(w + bits_off)[0];
+  if (nm <= 0) return;  // n == 0 or the in-kernel path: nbox_out is already written
+  const int W = (nm + 31) >> 5, capw = bitcap >> 5;
+  const double* mpoly = reinterpret_cast<const double*>(w);
+  const double* mscore = mpoly + (long)max_cand * 8;
+  const int32_t* order = reinterpret_cast<const int32_t*>(w + ((long)max_cand * (2 * (64 + 8)) + (long)3 * LANMS_T * CARRY_W * 8));
+  const uint32_t* bits = reinterpret_cast<const uint32_t*>(w + bits_off + 64);
+  float* ob = boxes_out + (long)pg * max_cand * 9;
+  constexpr int KW = NMS_BITW / 64;
+  uint32_t sup[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) sup[k] = 0u;
+  int nk = 0;
+  for (int i = 0; i < nm; ++i) {
+    const int wi = i >> 5, owner = wi & 63, slot = wi >> 6;
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) mine = (k == slot) ? sup[k] : mine;
+    const uint32_t word = __shfl(mine, owner);
+    if ((word >> (i & 31)) & 1u) continue;  // suppressed (wave-uniform)
+    const int idx = order[i];
+    if (lane < 9) ob[(long)nk * 9 + lane] = lane < 8 ? (float)mpoly[(long)idx * 8 + lane] : (float)mscore[idx];
+    ++nk;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int wd = lane + 64 * k;
+      if (wd < W) sup[k] |= bits[(long)i * capw + wd];
+    }
+  }
+  if (lane == 0) nbox_out[pg] = nk;
+}
+
 extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N, int max_cand, double iou_thr, float* boxes_out,
                                 int32_t* nbox_out, void* workspace, void* stream) {
   if (!cand || !counts || !boxes_out || !nbox_out || !workspace || N <= 0 || max_cand <= 0) return MSOCR_E_ARG;
@@ -639,9 +724,22 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
   long long* dbg = nullptr;
   const bool want_dbg = getenv("MSOCR_LANMS_DEBUG") != nullptr;  // diagnostic only: synchronises and prints phase times
   if (want_dbg && hipMalloc(&dbg, sizeof(long long) * 8 * N) != hipSuccess) dbg = nullptr;
+  const int bits_on = getenv("MSOCR_LANMS_BITS") ? atoi(getenv("MSOCR_LANMS_BITS")) : 1;  // 0: greedy pass inside the page kernel (diagnostic)
+  const long bits_off = lanms_bits_off(max_cand);
+  const int bitcap = bits_on ? nms_bitcap(max_cand) : 0;
   MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(LANMS_T), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
-                     (char*)workspace, stride, dbg);
-  const int rc = LAUNCH_OK();
+                     (char*)workspace, stride, dbg, bits_off, bitcap);
+  int rc = LAUNCH_OK();
+  if (rc == MSOCR_OK && bitcap > 0) {
+    MSOCR_LAUNCH(lanms_iou_bits_kernel, dim3(64, N), dim3(256), 0, (hipStream_t)stream, (char*)workspace, stride, max_cand, iou_thr, bits_off,
+                 bitcap);
+    rc = LAUNCH_OK();
+    if (rc == MSOCR_OK) {
+      MSOCR_LAUNCH(lanms_greedy_bits_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (char*)workspace, stride, max_cand, bits_off, bitcap,
+                   boxes_out, nbox_out);
+      rc = LAUNCH_OK();
+    }
+  }
   if (dbg) {
     long long* h = (long long*)malloc(sizeof(long long) * 8 * N);
     (void)hipStreamSynchronize((hipStream_t)stream);

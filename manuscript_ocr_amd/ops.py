@@ -271,6 +271,25 @@ def east_box_tail(boxes, nbox, expand_w, expand_h, scale_x, scale_y, axis_aligne
     return out, n_out
 
 
+def reading_order_crops(boxes, nbox, page_hw, min_text_size, img_h, img_w, page_base=0, y_tol_ratio=0.6, x_gap_ratio=float("inf")):
+    """Final boxes [N,max_cand,9] f32 + counts [N] i32 (device, from east_box_tail) -> per page, on the device: reading order of
+    the words, which positions yield a crop, and the crop descriptors for crop_resize_pad (msocr_reading_order_crops).
+    Returns (order [N,max_cand] i32, keep [N,max_cand] i32, desc [N,max_cand,8] i32, ncrop [N] i32; ncrop -1 = host path)."""
+    _need_cuda(boxes, nbox)
+    N, max_cand, _ = boxes.shape
+    dev = boxes.device
+    ws = torch.empty((nat.lib().msocr_reading_order_workspace_bytes(N, max_cand),), dtype=torch.uint8, device=dev)
+    order = torch.empty((N, max_cand), dtype=torch.int32, device=dev)
+    keep = torch.empty((N, max_cand), dtype=torch.int32, device=dev)
+    desc = torch.empty((N, max_cand, 8), dtype=torch.int32, device=dev)
+    ncrop = torch.empty((N,), dtype=torch.int32, device=dev)
+    nat.check(nat.lib().msocr_reading_order_crops(boxes.data_ptr(), nbox.data_ptr(), N, max_cand, int(page_hw[0]), int(page_hw[1]),
+                                                  int(min_text_size), int(img_h), int(img_w), float(y_tol_ratio), float(x_gap_ratio),
+                                                  int(page_base), order.data_ptr(), keep.data_ptr(), desc.data_ptr(), ncrop.data_ptr(),
+                                                  ws.data_ptr(), _stream()), "reading_order_crops")
+    return order, keep, desc, ncrop
+
+
 def nchw_to_nhwc(x_f32, dtype, out=None):
     _need_cuda(x_f32)
     N, C, H, W = x_f32.shape
@@ -380,17 +399,22 @@ def _crop_descriptors_loop(boxes, page_ids, page_hw, img_h, img_w):
 
 def crop_resize_pad(pages_u8, desc_host, img_h, img_w, desc_dev=None):
     """pages [N,H,W,3] u8 device, desc_host int32 [M,8] (numpy) -> canvases [M,img_h,img_w,3] u8 device.
-    desc_dev: the same descriptors already on the device (uploaded by the caller on another stream)."""
-    _need_cuda(pages_u8)
+    desc_dev: the same descriptors already on the device (uploaded by the caller on another stream); desc_host may be None
+    when they were produced on the device (reading_order_crops): the kernel then validates every descriptor itself."""
+    _need_cuda(pages_u8, desc_dev)
     N, H, W, C = pages_u8.shape
     assert C == 3 and pages_u8.dtype == torch.uint8 and pages_u8.is_contiguous()
-    M = len(desc_host)
-    desc_host = desc_host.astype("int32", copy=False)
+    hp = None
+    if desc_host is not None:
+        desc_host = desc_host.astype("int32", copy=False)
+        hp = desc_host.ctypes.data
+    M = len(desc_host) if desc_host is not None else int(desc_dev.shape[0])
     if desc_dev is None:
         desc_dev = torch.from_numpy(desc_host).to(pages_u8.device)
     else:
+        assert desc_dev.dtype == torch.int32 and desc_dev.is_contiguous() and desc_dev.shape == (M, 8)
         desc_dev.record_stream(torch.cuda.current_stream())
     out = torch.empty((M, img_h, img_w, 3), dtype=torch.uint8, device=pages_u8.device)
-    nat.check(nat.lib().msocr_crop_resize_pad(pages_u8.data_ptr(), N, H, W, desc_dev.data_ptr(), desc_host.ctypes.data, M, img_h, img_w,
+    nat.check(nat.lib().msocr_crop_resize_pad(pages_u8.data_ptr(), N, H, W, desc_dev.data_ptr(), hp, M, img_h, img_w,
                                               out.data_ptr(), _stream()), "crop_resize_pad")
     return out

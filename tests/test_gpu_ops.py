@@ -355,6 +355,27 @@ def test_lanms_many_unmerged_polygons_general_nms_path(ops):
     assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,bits", [(4300, "0"), (1500, "0"), (9000, "1")])
+def test_lanms_nms_path_variants(ops, monkeypatch, n, bits):
+    """The greedy pass of standard_nms has three implementations that must all equal the oracle bit for bit: the chip-wide IoU
+    bit matrix + single-wave replay (default, up to 8192 merged polygons), and — MSOCR_LANMS_BITS=0, or above 8192 — the two
+    in-kernel loops of the page kernel (polygons in registers up to 4096, in memory beyond)."""
+    from oracle import lanms as L
+    monkeypatch.setenv("MSOCR_LANMS_BITS", bits)
+    rng = np.random.default_rng(n)
+    span = 9000 if n > 5000 else 6000
+    cx, cy = rng.uniform(50, span, n), rng.uniform(50, span, n)
+    w, h = rng.uniform(10, 60, n), rng.uniform(6, 20, n)
+    inp = np.stack([cx - w, cy - h, cx + w, cy - h, cx + w, cy + h, cx - w, cy + h, rng.uniform(0.1, 1.0, n)], axis=1).astype(np.float32)
+    exp, nm = L.locality_aware_nms(inp, 0.2, return_merged_count=True)
+    assert (nm > 8192) if n == 9000 else (nm > 4096) == (n == 4300)
+    cand = torch.from_numpy(inp).cuda()[None].contiguous()
+    boxes, nbox = ops.east_lanms(cand, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.2)
+    nb = int(nbox.cpu()[0])
+    assert nb == len(exp) and nb < nm
+    assert np.array_equal(boxes[0, :nb].cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
 def _random_quads(rng, M, trial):
     cx, cy = rng.random(M) * 1800, rng.random(M) * 1400
     w, h = rng.random(M) * 150 + 2, rng.random(M) * 40 + 2

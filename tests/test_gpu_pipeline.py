@@ -297,3 +297,84 @@ def test_device_box_tail_equals_host_tail_end_to_end(gpu):
         for rc, rb in zip(c, b):
             assert [(w.polygon, w.detection_confidence) for w in rc["page"].blocks[0].words] == \
                    [(w.polygon, w.detection_confidence) for w in rb["page"].blocks[0].words]
+
+
+def _ro_case(ops, boxes_i, page_hw, img_hw=(32, 100), min_text=5):
+    """Device reading order + descriptors for one page of integer AABBs -> (order, keep, desc) as numpy."""
+    n = len(boxes_i)
+    cap = max(n, 1) + 3
+    q = np.zeros((1, cap, 9), dtype=np.float32)
+    for i, (x0, y0, x1, y1) in enumerate(boxes_i):
+        q[0, i, :8] = (x0 + 0.25, y0 + 0.5, x1 + 0.75, y0 + 0.25, x1 + 0.5, y1 + 0.75, x0 + 0.5, y1 + 0.25) if min(x0, y0) >= 0 else \
+            (x0, y0, x1, y0, x1, y1, x0, y1)  # fractional parts exercise the int32 truncation (toward zero)
+        q[0, i, 8] = 0.9
+    order, keep, desc, nc = ops.reading_order_crops(torch.from_numpy(q).cuda(), torch.tensor([n], dtype=torch.int32).cuda(), page_hw, min_text,
+                                                    img_hw[0], img_hw[1], page_base=0)
+    nc = int(nc[0])
+    return order[0, :n].cpu().numpy(), keep[0, :n].cpu().numpy(), desc[0, :max(nc, 0)].cpu().numpy(), nc
+
+
+def test_device_reading_order_matches_host_and_reference_goldens(gpu, golden_dir):
+    """msocr_reading_order_crops (one workgroup per page) against (a) the reference's own outputs for
+    sort_boxes_reading_order_with_resolutions (tests/golden/pipeline_glue.json), (b) the host helper msocr_reading_order_host
+    and the host descriptor arithmetic (ops.crop_descriptors) on random layouts with overlaps, duplicates, nested boxes, tiny
+    boxes and boxes sticking out of the page: order, crop flags and descriptors bit-identical."""
+    import json
+    from manuscript_ocr_amd import _native as nat
+    from manuscript_ocr_amd import ops, synth
+    from manuscript_ocr_amd._pipeline import _reading_order
+    with open(os.path.join(golden_dir, "pipeline_glue.json")) as f:
+        cases = json.load(f)
+    for case in cases:
+        boxes = [tuple(b) for b in case["boxes"]]
+        if not boxes:
+            continue
+        order, keep, desc, nc = _ro_case(ops, boxes, (2000, 2000))
+        assert [list(boxes[k]) for k in order] == case["sorted_res"], case["boxes"][:4]
+    rng = np.random.default_rng(12)
+    for trial in range(12):
+        H, W = 700, 1000
+        rects = synth.synth_layout(int(rng.integers(1 << 30)), H, W)
+        b = [[int(v) for v in (r + rng.integers(-8, 9, size=4))] for r in rects]
+        if trial % 3 == 0:  # duplicates and nested boxes
+            b += [list(b[0]), list(b[3]), [b[5][0] + 3, b[5][1] + 2, b[5][2] - 3, b[5][3] - 2]]
+        if trial % 4 == 1:  # heavy overlaps: several sweeps of the shrink loop
+            b += [[x0 + 20, y0 + 6, x1 + 25, y1 + 9] for x0, y0, x1, y1 in b[::3]]
+        if trial % 2 == 0:  # tiny and out-of-page boxes
+            b += [[5, 5, 8, 9], [W - 10, H - 12, W + 30, H + 20], [-20, -10, 40, 30], [10, 10, 10, 40]]
+        b = [bb for bb in b if bb[2] >= bb[0] and bb[3] >= bb[1]]
+        order, keep, desc, nc = _ro_case(ops, b, (H, W))
+        exp_order = _reading_order(np.asarray(b, dtype=np.int32))
+        assert order.tolist() == exp_order, trial
+        ordered = [b[k] for k in exp_order]
+        big = [(bx[2] - bx[0]) >= 5 and (bx[3] - bx[1]) >= 5 for bx in ordered]
+        d_exp, k_exp = ops.crop_descriptors([bx for bx, g in zip(ordered, big) if g], [0] * sum(big), (H, W), 32, 100)
+        keep_exp = np.zeros(len(b), dtype=np.int32)
+        keep_exp[np.flatnonzero(big)[k_exp]] = 1
+        assert np.array_equal(keep, keep_exp), trial
+        assert nc == len(d_exp) and np.array_equal(desc, d_exp), trial
+
+
+def test_predict_batch_device_order_equals_host_order(gpu):
+    """Pipeline.predict_batch with the device reading-order / descriptor kernel (default) == the host path (device_order=False):
+    same words in the same order, same texts and confidences, on pages with overlapping boxes."""
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    H, W = 512, 768
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    det = EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda", expand_ratio_w=1.6)  # wide expansion: overlaps
+    rec = TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda")
+    pipe = Pipeline(detector=det, recognizer=rec)
+    pages, maps = [], []
+    for seed in (51, 52, 53):
+        pg, rects = synth.synth_page(seed, H, W)
+        pages.append(pg)
+        maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+    mo = (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())
+    a = pipe.predict_batch(pages, _maps_override=mo)
+    pipe.device_order = False
+    b = pipe.predict_batch(pages, _maps_override=mo)
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    assert [key(p) for p in a] == [key(p) for p in b]
+    assert sum(len(p.blocks[0].words) for p in a) > 60 and any(w.text for p in a for w in p.blocks[0].words)
