@@ -231,6 +231,31 @@ int msocr_reading_order_crops(const float* boxes, const int32_t* nbox, int N, in
                               int32_t* order_out, int32_t* keep_out, int32_t* desc_out, int32_t* ncrop_out, void* workspace,
                               void* stream);
 
+/* ---- image ingest: JPEG -> RGB on the device -------------------------------------------------------------------------
+ * Replaces the file decode of read_image (detectors/_east/utils.py:477-497: cv2.imread / PIL = libjpeg-turbo defaults).
+ * 8-bit baseline / extended-sequential Huffman JPEG, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart
+ * markers.  The serial entropy decode runs on the HOST (msocr_jpeg_parse_host fills `info`; msocr_jpeg_entropy_decode_host
+ * writes the quantised coefficients, natural order, component after component: [blocks_h][blocks_w][64] int16 at coef_off[c]);
+ * dequantisation + inverse DCT (libjpeg "islow"), fancy chroma upsampling and YCbCr->RGB run on the DEVICE
+ * (msocr_jpeg_reconstruct: coef_dev = the same array in device memory, workspace = msocr_jpeg_workspace_bytes(info) bytes,
+ * rgb_out [height][width][3] u8).  msocr_jpeg_reconstruct_host is the HOST twin of the device stage (same code; all pointers
+ * host memory).  Unsupported or corrupt streams: MSOCR_E_ARG / info.supported = 0 -> use the host decoder. */
+typedef struct msocr_jpeg_info {
+  int32_t width, height, ncomp;   /* ncomp 1 (grayscale) or 3 (YCbCr) */
+  int32_t hs[3], vs[3];           /* sampling factors per component */
+  int32_t blocks_w[3], blocks_h[3]; /* component planes in 8x8 blocks, padded to whole MCUs */
+  int32_t supported;
+  int64_t coef_off[3];            /* int16 elements */
+  int64_t coef_total;
+  uint16_t quant[3][64];          /* natural order */
+} msocr_jpeg_info;
+int msocr_jpeg_parse_host(const uint8_t* data_host, int64_t len, msocr_jpeg_info* info_out);
+int msocr_jpeg_entropy_decode_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int16_t* coef_out_host);
+int64_t msocr_jpeg_workspace_bytes(const msocr_jpeg_info* info);
+int msocr_jpeg_reconstruct(const msocr_jpeg_info* info, const int16_t* coef_dev, void* workspace_dev, uint8_t* rgb_out_dev,
+                           void* stream);
+int msocr_jpeg_reconstruct_host(const msocr_jpeg_info* info, const int16_t* coef_host, uint8_t* rgb_out_host);
+
 /* f32 <-> bf16 / layout helpers */
 int msocr_nchw_f32_to_nhwc(const float* in, int N, int C, int H, int W, int dtype, void* out, int64_t out_ld,
                            void* stream);

@@ -30,6 +30,12 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class JpegInfo(ctypes.Structure):
+    _fields_ = [("width", c_i32), ("height", c_i32), ("ncomp", c_i32), ("hs", c_i32 * 3), ("vs", c_i32 * 3),
+                ("blocks_w", c_i32 * 3), ("blocks_h", c_i32 * 3), ("supported", c_i32), ("coef_off", c_i64 * 3),
+                ("coef_total", c_i64), ("quant", (ctypes.c_uint16 * 64) * 3)]
+
+
 class AttnWeights(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("h2h_wt", "h2h_b", "score_w", "wih_ctx_t", "wih_tok", "whh_t", "b_gates", "gen_wt", "gen_b")]
 
@@ -68,6 +74,11 @@ _SIGS = {
     "msocr_reading_order_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "msocr_reading_order_crops": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_jpeg_parse_host": (c_i32, [c_vp, c_i64, ctypes.POINTER(JpegInfo)]),
+    "msocr_jpeg_entropy_decode_host": (c_i32, [c_vp, c_i64, ctypes.POINTER(JpegInfo), c_vp]),
+    "msocr_jpeg_workspace_bytes": (c_i64, [ctypes.POINTER(JpegInfo)]),
+    "msocr_jpeg_reconstruct": (c_i32, [ctypes.POINTER(JpegInfo), c_vp, c_vp, c_vp, c_vp]),
+    "msocr_jpeg_reconstruct_host": (c_i32, [ctypes.POINTER(JpegInfo), c_vp, c_vp]),
     "msocr_nchw_f32_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "msocr_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "msocr_version": (ctypes.c_char_p, []),

@@ -108,10 +108,9 @@ class Pipeline:
                 and getattr(self, "native_fast_path", True)):
             # both plugins are this package's: same result through the device path (crops cut, resized and padded on the
             # device from the uploaded page, one recogniser pass) — tests/test_gpu_pipeline.py pins batch == per-page
-            image_array = read_image(image)
-            page = self.predict_batch([image_array])[0]
+            page = self.predict_batch([image])[0]  # a JPEG path is decoded on the device (ingest.py), arrays are uploaded
             if vis:
-                pil = image if isinstance(image, Image.Image) else Image.fromarray(image_array)
+                pil = image if isinstance(image, Image.Image) else Image.fromarray(read_image(image))
                 return page, visualize_page(pil, page, show_order=True)
             return page
         start = time.time()
@@ -194,12 +193,30 @@ class Pipeline:
         import torch
 
         det = self.detector
-        arrays = [read_image(im) for im in images]
+        # image ingest: a JPEG file is decoded ON THE DEVICE (host Huffman stage + HIP reconstruction, ingest.py) — the page's
+        # pixels never exist on the host, `arrays` then only carries the shape; everything else goes through read_image
+        arrays, decoded = [], []
+        for im in images:
+            t = None
+            if pages_dev is None and getattr(self, "device_ingest", True):
+                from . import ingest
+                t = ingest.read_image_device(im, det.device)
+            if t is not None:
+                arrays.append(np.broadcast_to(np.uint8(0), tuple(t.shape)))
+            else:
+                arrays.append(read_image(im))
+            decoded.append(t)
         if len({a.shape for a in arrays}) != 1:
             raise ValueError("predict_batch needs equally sized pages")
         N = len(arrays)
         if pages_dev is None:
-            pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(det.device)
+            if all(t is not None for t in decoded):
+                pages_dev = torch.stack(decoded)
+            elif not any(t is not None for t in decoded):
+                pages_dev = torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(det.device)
+            else:
+                pages_dev = torch.stack([t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(det.device)
+                                         for t, a in zip(decoded, arrays)])
         nsub = sub_batches or min(8, max(1, N // 2))  # >= 2 pages per group; 8 groups measured best at 16 pages
         nsub = max(1, min(nsub, N))
         bounds = [(N * k // nsub, N * (k + 1) // nsub) for k in range(nsub)]

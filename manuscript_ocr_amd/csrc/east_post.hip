@@ -188,8 +188,122 @@ __device__ __forceinline__ bool d_surely_disjoint(const double* p1, const double
   return (l1 > r2 + margin) || (l2 > r1 + margin) || (t1 > b2 + margin) || (t2 > b1 + margin);
 }
 __device__ int g_lanms_shortcut = 1;
+
+// ---- register-resident polygon_iou for the common case ------------------------------------------------------------------
+// d_polygon_iou keeps its two clip buffers (2 x 20 vertices, dynamically indexed) in scratch memory, i.e. every vertex of
+// every Sutherland-Hodgman stage is a round trip through the memory pipeline: ~40 us per call, and the sequential merge scan
+// is a chain of such calls.  Clipping a quad by the four half-planes of a convex quad never holds more than 8 vertices, so
+// this variant keeps the polygon in 8 + 8 registers with statically indexed (fully unrolled, predicated) loops and a select
+// chain for the one dynamic operation, "append at position count".  It performs the reference's operations in the
+// reference's order (lanms.py:17-91) — same values bit for bit — and reports failure the moment a stage would hold a 9th
+// vertex (possible only for non-convex / self-intersecting quads); the caller then runs the general version.
+struct Poly8 {
+  double x[8], y[8];
+  int n;
+};
+__device__ __forceinline__ void p8_push(Poly8& o, double px, double py, bool& over) {
+  if (o.n >= 8) { over = true; return; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o.x[k] = (o.n == k) ? px : o.x[k];
+    o.y[k] = (o.n == k) ? py : o.y[k];
+  }
+  ++o.n;
+}
+__device__ __forceinline__ void p8_clip(const Poly8& s, double Ax, double Ay, double Bx, double By, Poly8& o, bool& over) {
+  o.n = 0;
+  // prev of vertex 0 is vertex n-1
+  double px = s.x[0], py = s.y[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    px = (s.n - 1 == k) ? s.x[k] : px;
+    py = (s.n - 1 == k) ? s.y[k] : py;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < s.n) {
+      const double cx = s.x[i], cy = s.y[i];
+      const bool curr_in = (Bx - Ax) * (cy - Ay) - (By - Ay) * (cx - Ax) >= 0;
+      const bool prev_in = (Bx - Ax) * (py - Ay) - (By - Ay) * (px - Ax) >= 0;
+      if (curr_in != prev_in) {  // compute_intersection(prev, curr, A, B)  (lanms.py:17-29)
+        const double BAx = cx - px, BAy = cy - py;
+        const double DCx = Bx - Ax, DCy = By - Ay;
+        const double denom = BAx * DCy - BAy * DCx;
+        const double CAx = Ax - px, CAy = Ay - py;
+        double ix = px, iy = py;
+        if (denom != 0) {
+          const double t = (CAx * DCy - CAy * DCx) / denom;
+          ix = px + t * BAx;
+          iy = py + t * BAy;
+        }
+        p8_push(o, ix, iy, over);
+      }
+      if (curr_in) p8_push(o, cx, cy, over);
+      px = cx;
+      py = cy;
+    }
+  }
+}
+__device__ __forceinline__ double p8_area(const Poly8& p) {  // polygon_area (lanms.py:7-14)
+  double area = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < p.n) {
+      const double xj = (i + 1 < p.n && i + 1 < 8) ? p.x[(i + 1) & 7] : p.x[0];
+      const double yj = (i + 1 < p.n && i + 1 < 8) ? p.y[(i + 1) & 7] : p.y[0];
+      area += p.x[i] * yj - xj * p.y[i];
+    }
+  }
+  return fabs(area) / 2.0;
+}
+// returns false (result unspecified) when a clip stage needs more than 8 vertices
+__device__ __forceinline__ bool d_polygon_iou_fast(const double* poly1, const double* poly2, double* iou) {
+  Poly8 a, b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a.x[k] = 0.0; a.y[k] = 0.0; b.x[k] = 0.0; b.y[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a.x[k] = poly1[2 * k]; a.y[k] = poly1[2 * k + 1]; }
+  a.n = 4;
+  bool over = false;
+  // the four clip stages of polygon_intersection (lanms.py:60-77); the live polygon alternates between b and a
+  p8_clip(a, poly2[0], poly2[1], poly2[2], poly2[3], b, over);
+  int cnt = b.n;
+  bool in_a = false;
+  if (cnt != 0) {
+    p8_clip(b, poly2[2], poly2[3], poly2[4], poly2[5], a, over);
+    cnt = a.n;
+    in_a = true;
+    if (cnt != 0) {
+      p8_clip(a, poly2[4], poly2[5], poly2[6], poly2[7], b, over);
+      cnt = b.n;
+      in_a = false;
+      if (cnt != 0) {
+        p8_clip(b, poly2[6], poly2[7], poly2[0], poly2[1], a, over);
+        cnt = a.n;
+        in_a = true;
+      }
+    }
+  }
+  if (over) return false;
+  double inter_area = 0.0;
+  if (cnt > 2) inter_area = in_a ? p8_area(a) : p8_area(b);
+  double s1 = 0.0, s2 = 0.0;  // polygon_area of the two quads (lanms.py:7-14)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) & 3;
+    s1 += poly1[2 * i] * poly1[2 * j + 1] - poly1[2 * j] * poly1[2 * i + 1];
+    s2 += poly2[2 * i] * poly2[2 * j + 1] - poly2[2 * j] * poly2[2 * i + 1];
+  }
+  const double area1 = fabs(s1) / 2.0, area2 = fabs(s2) / 2.0;
+  const double union_area = area1 + area2 - inter_area;
+  *iou = union_area <= 0 ? 0.0 : inter_area / union_area;
+  return true;
+}
+__device__ int g_lanms_fastclip = 1;
 __device__ __forceinline__ double d_polygon_iou_q(const double* poly1, const double* poly2) {
   if (g_lanms_shortcut && d_surely_disjoint(poly1, poly2)) return 0.0;
+  double r;
+  if (g_lanms_fastclip && d_polygon_iou_fast(poly1, poly2, &r)) return r;
   return d_polygon_iou(poly1, poly2);
 }
 
@@ -712,6 +826,13 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
     if (v != cur) {
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_lanms_shortcut), &v, sizeof(int)) != hipSuccess) return MSOCR_E_LAUNCH;
       cur = v;
+    }
+    const char* f = getenv("MSOCR_LANMS_FASTCLIP");  // 0: always the general (scratch-buffer) polygon clip (diagnostic)
+    const int vf = (f && f[0] == '0') ? 0 : 1;
+    static int curf = -1;
+    if (vf != curf) {
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_lanms_fastclip), &vf, sizeof(int)) != hipSuccess) return MSOCR_E_LAUNCH;
+      curf = vf;
     }
   }
   {

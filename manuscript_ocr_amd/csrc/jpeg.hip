@@ -1,0 +1,528 @@
+// jpeg.hip — image ingest: baseline JPEG -> RGB u8 on the device.
+//
+// Replaces read_image's file decode (detectors/_east/utils.py:477-497: cv2.imread / PIL, both libjpeg-turbo with its default
+// decompression settings: JDCT_ISLOW, fancy upsampling, JFIF YCbCr -> RGB) for the formats a scanner / camera page comes in:
+// 8-bit baseline or extended-sequential Huffman JPEG, grayscale or YCbCr with 4:4:4, 4:2:2 (h2v1) or 4:2:0 (h2v2) sampling,
+// one interleaved scan, restart markers.  Anything else (progressive, arithmetic, CMYK, 12-bit, multi-scan, h1v2) is reported
+// as unsupported and the caller falls back to the host decoder.
+//
+// Split: the entropy-coded segment is a serial bit stream, so parsing + Huffman decoding run on the HOST
+// (msocr_jpeg_parse_host / msocr_jpeg_entropy_decode_host -> quantised DCT coefficients, 2 bytes each); everything per-pixel —
+// dequantisation + inverse DCT, chroma upsampling, colour conversion — runs on the DEVICE (msocr_jpeg_reconstruct), so the
+// page's pixels are produced in HBM and never cross PCIe.  The reconstruction arithmetic is libjpeg's, restated from its
+// published algorithms (jidctint.c "islow" 13-bit fixed point, jdsample.c triangle-filter upsampling, jdcolor.c 16-bit YCC
+// tables) in __host__ __device__ functions: msocr_jpeg_reconstruct_host runs the same code on the CPU, which is how the CPU
+// test-suite pins it bit for bit against PIL's decode of the same files.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "msocr.h"
+
+#define MSOCR_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define HD __host__ __device__ __forceinline__
+
+namespace {
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---------------------------------------------------------------------------------------------------- host: parse + Huffman
+struct HuffTable {
+  bool present = false;
+  uint8_t bits[17] = {0}, vals[256] = {0};
+  // fast path: 9-bit lookahead -> (length << 8) | symbol, 0 = longer code
+  uint16_t look[512];
+  int32_t maxcode[18];  // largest code of each length (-1 none), [17] = sentinel
+  int32_t valoff[17];
+  void build() {
+    int code = 0, k = 0;
+    int32_t huffcode[256];
+    uint8_t huffsize[256];
+    for (int l = 1; l <= 16; ++l)
+      for (int i = 0; i < bits[l]; ++i) { huffsize[k] = (uint8_t)l; ++k; }
+    const int n = k;
+    k = 0;
+    int si = n ? huffsize[0] : 0;
+    while (k < n) {
+      while (k < n && huffsize[k] == si) huffcode[k++] = code++;
+      code <<= 1;
+      ++si;
+    }
+    int p = 0;
+    for (int l = 1; l <= 16; ++l) {
+      if (bits[l]) {
+        valoff[l] = p - huffcode[p];
+        p += bits[l];
+        maxcode[l] = huffcode[p - 1];
+      } else {
+        maxcode[l] = -1;
+        valoff[l] = 0;
+      }
+    }
+    maxcode[17] = 0x7fffffff;
+    memset(look, 0, sizeof(look));
+    p = 0;
+    for (int l = 1; l <= 9; ++l)
+      for (int i = 0; i < bits[l]; ++i, ++p) {
+        const int base = huffcode[p] << (9 - l);
+        for (int c = 0; c < (1 << (9 - l)); ++c) look[base + c] = (uint16_t)((l << 8) | vals[p]);
+      }
+  }
+};
+
+struct BitReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint64_t acc = 0;
+  int nbits = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (nbits <= 56) {
+      int b = 0;
+      if (!hit_marker && p < end) {
+        b = *p;
+        if (b == 0xFF) {
+          if (p + 1 < end && p[1] == 0x00) p += 2;     // stuffed byte
+          else { hit_marker = true; b = 0; }           // a marker: feed zeros (libjpeg does the same past the end of a segment)
+        } else {
+          ++p;
+        }
+      }
+      acc = (acc << 8) | (uint64_t)b;
+      nbits += 8;
+    }
+  }
+  inline int peek(int n) { if (nbits < n) fill(); return (int)((acc >> (nbits - n)) & ((1u << n) - 1)); }
+  inline void skip(int n) { nbits -= n; }
+  inline int get(int n) { if (n == 0) return 0; const int v = peek(n); skip(n); return v; }
+  void restart() { acc = 0; nbits = 0; hit_marker = false; }
+};
+
+inline int huff_decode(BitReader& br, const HuffTable& t) {
+  const int look = br.peek(9);
+  const uint16_t e = t.look[look];
+  if (e) { br.skip(e >> 8); return e & 0xff; }
+  int code = look, l = 9;
+  for (;;) {  // codes longer than 9 bits
+    ++l;
+    if (l > 16) return -1;
+    code = br.peek(l);
+    if (code <= t.maxcode[l] && t.maxcode[l] >= 0) break;
+  }
+  br.skip(l);
+  return t.vals[(code + t.valoff[l]) & 0xff];
+}
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }  // HUFF_EXTEND
+
+struct Parsed {
+  msocr_jpeg_info info;
+  HuffTable dc[4], ac[4];
+  int dc_sel[3], ac_sel[3];
+  int restart_interval = 0;
+  const uint8_t* scan = nullptr;  // first byte of the entropy-coded segment
+  int mcus_x = 0, mcus_y = 0;
+};
+
+inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+// Walks the markers up to the first SOS.  Returns MSOCR_OK, or MSOCR_E_ARG for a corrupt / unsupported stream.
+int parse(const uint8_t* d, int64_t len, Parsed* P) {
+  memset(&P->info, 0, sizeof(P->info));
+  if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) return MSOCR_E_ARG;
+  uint16_t qt[4][64];
+  bool qt_present[4] = {false, false, false, false};
+  int qsel[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
+  bool have_sof = false, adobe = false;
+  int adobe_transform = -1;
+  int64_t i = 2;
+  while (i + 4 <= len) {
+    if (d[i] != 0xFF) return MSOCR_E_ARG;
+    while (i < len && d[i] == 0xFF) ++i;  // fill bytes
+    if (i >= len) return MSOCR_E_ARG;
+    const int m = d[i++];
+    if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (m == 0xD9) return MSOCR_E_ARG;
+    if (i + 2 > len) return MSOCR_E_ARG;
+    const int L = rd16(d + i);
+    if (L < 2 || i + L > len) return MSOCR_E_ARG;
+    const uint8_t* s = d + i + 2;
+    const int n = L - 2;
+    if (m == 0xDB) {  // DQT
+      int o = 0;
+      while (o < n) {
+        const int pq = s[o] >> 4, tq = s[o] & 15;
+        ++o;
+        if (tq > 3 || pq > 1 || o + 64 * (pq + 1) > n) return MSOCR_E_ARG;
+        for (int k = 0; k < 64; ++k) {
+          qt[tq][kZigzag[k]] = pq ? (uint16_t)rd16(s + o + 2 * k) : s[o + k];
+        }
+        o += 64 * (pq + 1);
+        qt_present[tq] = true;
+      }
+    } else if (m == 0xC4) {  // DHT
+      int o = 0;
+      while (o < n) {
+        if (o + 17 > n) return MSOCR_E_ARG;
+        const int tc = s[o] >> 4, th = s[o] & 15;
+        if (tc > 1 || th > 3) return MSOCR_E_ARG;
+        HuffTable& t = tc ? P->ac[th] : P->dc[th];
+        int cnt = 0;
+        t.bits[0] = 0;
+        for (int l = 1; l <= 16; ++l) { t.bits[l] = s[o + l]; cnt += t.bits[l]; }
+        o += 17;
+        if (cnt > 256 || o + cnt > n) return MSOCR_E_ARG;
+        memcpy(t.vals, s + o, cnt);
+        o += cnt;
+        t.present = true;
+        t.build();
+      }
+    } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: baseline / extended sequential, Huffman
+      if (n < 6 || have_sof) return MSOCR_E_ARG;
+      if (s[0] != 8) return MSOCR_E_ARG;
+      P->info.height = rd16(s + 1);
+      P->info.width = rd16(s + 3);
+      P->info.ncomp = s[5];
+      if (P->info.height <= 0 || P->info.width <= 0 || (P->info.ncomp != 1 && P->info.ncomp != 3) || n < 6 + 3 * P->info.ncomp)
+        return MSOCR_E_ARG;
+      for (int c = 0; c < P->info.ncomp; ++c) {
+        comp_id[c] = s[6 + 3 * c];
+        P->info.hs[c] = s[7 + 3 * c] >> 4;
+        P->info.vs[c] = s[7 + 3 * c] & 15;
+        qsel[c] = s[8 + 3 * c];
+        if (qsel[c] > 3) return MSOCR_E_ARG;
+      }
+      have_sof = true;
+    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return MSOCR_E_ARG;  // progressive / lossless / arithmetic / hierarchical: host decoder
+    } else if (m == 0xDD) {
+      if (n < 2) return MSOCR_E_ARG;
+      P->restart_interval = rd16(s);
+    } else if (m == 0xEE && n >= 12 && memcmp(s, "Adobe", 5) == 0) {
+      adobe = true;
+      adobe_transform = s[11];
+    } else if (m == 0xDA) {  // SOS
+      if (!have_sof || n < 1) return MSOCR_E_ARG;
+      const int ns = s[0];
+      if (ns != P->info.ncomp || n < 1 + 2 * ns + 3) return MSOCR_E_ARG;  // one interleaved scan with every component
+      for (int k = 0; k < ns; ++k) {
+        int c = -1;
+        for (int q = 0; q < P->info.ncomp; ++q)
+          if (comp_id[q] == s[1 + 2 * k]) c = q;
+        if (c != k) return MSOCR_E_ARG;  // scan order = frame order (what every baseline encoder writes)
+        P->dc_sel[c] = s[2 + 2 * k] >> 4;
+        P->ac_sel[c] = s[2 + 2 * k] & 15;
+        if (P->dc_sel[c] > 3 || P->ac_sel[c] > 3 || !P->dc[P->dc_sel[c]].present || !P->ac[P->ac_sel[c]].present) return MSOCR_E_ARG;
+      }
+      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return MSOCR_E_ARG;
+      P->scan = d + i + L;
+      break;
+    }
+    i += L;
+  }
+  if (!P->scan) return MSOCR_E_ARG;
+  msocr_jpeg_info& f = P->info;
+  if (f.ncomp == 3) {
+    // colour space as libjpeg decides it (jdapimin.c default_decompress_parms): Adobe transform 0 = RGB / ids 'R','G','B' = RGB
+    if (adobe && adobe_transform == 0) return MSOCR_E_ARG;
+    if (!adobe && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return MSOCR_E_ARG;
+    if (f.hs[1] != 1 || f.vs[1] != 1 || f.hs[2] != 1 || f.vs[2] != 1) return MSOCR_E_ARG;
+    if (!((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 2))) return MSOCR_E_ARG;
+  } else {
+    f.hs[0] = f.vs[0] = 1;  // a single-component scan is non-interleaved: one block per MCU whatever the sampling factors say
+  }
+  const int hmax = f.hs[0], vmax = f.vs[0];
+  P->mcus_x = (f.width + 8 * hmax - 1) / (8 * hmax);
+  P->mcus_y = (f.height + 8 * vmax - 1) / (8 * vmax);
+  int64_t off = 0;
+  for (int c = 0; c < f.ncomp; ++c) {
+    if (!qt_present[qsel[c]]) return MSOCR_E_ARG;
+    for (int k = 0; k < 64; ++k) f.quant[c][k] = qt[qsel[c]][k];
+    f.blocks_w[c] = P->mcus_x * f.hs[c];
+    f.blocks_h[c] = P->mcus_y * f.vs[c];
+    f.coef_off[c] = off;
+    off += (int64_t)f.blocks_w[c] * f.blocks_h[c] * 64;
+  }
+  f.coef_total = off;
+  f.supported = 1;
+  return MSOCR_OK;
+}
+
+int entropy_decode(const Parsed& P, const uint8_t* end, int16_t* coef) {
+  const msocr_jpeg_info& f = P.info;
+  memset(coef, 0, sizeof(int16_t) * (size_t)f.coef_total);
+  BitReader br;
+  br.p = P.scan;
+  br.end = end;
+  int pred[3] = {0, 0, 0};
+  int until_restart = P.restart_interval;
+  for (int my = 0; my < P.mcus_y; ++my)
+    for (int mx = 0; mx < P.mcus_x; ++mx) {
+      if (P.restart_interval && until_restart == 0) {
+        // byte-align, expect RSTn
+        br.restart();
+        const uint8_t* q = br.p;
+        while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+        if (q + 1 >= end) return MSOCR_E_ARG;
+        br.p = q + 2;
+        pred[0] = pred[1] = pred[2] = 0;
+        until_restart = P.restart_interval;
+      }
+      for (int c = 0; c < f.ncomp; ++c) {
+        const HuffTable& dct = P.dc[P.dc_sel[c]];
+        const HuffTable& act = P.ac[P.ac_sel[c]];
+        for (int by = 0; by < f.vs[c]; ++by)
+          for (int bx = 0; bx < f.hs[c]; ++bx) {
+            int16_t* blk = coef + f.coef_off[c] + ((int64_t)(my * f.vs[c] + by) * f.blocks_w[c] + (mx * f.hs[c] + bx)) * 64;
+            int s = huff_decode(br, dct);
+            if (s < 0 || s > 15) return MSOCR_E_ARG;
+            if (s) pred[c] += extend(br.get(s), s);
+            blk[0] = (int16_t)pred[c];
+            for (int k = 1; k < 64;) {
+              const int rs = huff_decode(br, act);
+              if (rs < 0) return MSOCR_E_ARG;
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz == 0) {
+                if (r != 15) break;  // EOB
+                k += 16;
+                continue;
+              }
+              k += r;
+              if (k > 63) return MSOCR_E_ARG;
+              blk[kZigzag[k]] = (int16_t)extend(br.get(sz), sz);
+              ++k;
+            }
+          }
+      }
+      if (P.restart_interval) --until_restart;
+    }
+  return MSOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- reconstruction
+// jidctint.c, jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2
+#define C_0_298631336 2446
+#define C_0_390180644 3196
+#define C_0_541196100 4433
+#define C_0_765366865 6270
+#define C_0_899976223 7373
+#define C_1_175875602 9633
+#define C_1_501321110 12299
+#define C_1_847759065 15137
+#define C_1_961570560 16069
+#define C_2_053119869 16819
+#define C_2_562915447 20995
+#define C_3_072711026 25172
+
+HD int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+HD uint8_t idct_range_limit(int v) {  // sample_range_limit + CENTERJSAMPLE, indexed with (v & RANGE_MASK)
+  const int x = v & 1023;
+  return (uint8_t)(x < 128 ? x + 128 : (x < 512 ? 255 : (x < 896 ? 0 : x - 896)));
+}
+
+HD void idct_1d(int d0, int d1, int d2, int d3, int d4, int d5, int d6, int d7, int shift0, int o[8]) {
+  // even part; d0/d4 are shifted up by CONST_BITS by the caller's convention: tmp0 = (d0 + d4) << CONST_BITS
+  int z1 = (d2 + d6) * C_0_541196100;
+  const int t2 = z1 + d6 * (-C_1_847759065);
+  const int t3 = z1 + d2 * C_0_765366865;
+  const int t0 = (d0 + d4) * (1 << 13);
+  const int t1 = (d0 - d4) * (1 << 13);
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  // odd part
+  int a0 = d7, a1 = d5, a2 = d3, a3 = d1;
+  z1 = a0 + a3;
+  int z2 = a1 + a2, z3 = a0 + a2, z4 = a1 + a3;
+  const int z5 = (z3 + z4) * C_1_175875602;
+  a0 *= C_0_298631336; a1 *= C_2_053119869; a2 *= C_3_072711026; a3 *= C_1_501321110;
+  z1 *= -C_0_899976223; z2 *= -C_2_562915447; z3 *= -C_1_961570560; z4 *= -C_0_390180644;
+  z3 += z5; z4 += z5;
+  a0 += z1 + z3; a1 += z2 + z4; a2 += z2 + z3; a3 += z1 + z4;
+  o[0] = descale(t10 + a3, shift0); o[7] = descale(t10 - a3, shift0);
+  o[1] = descale(t11 + a2, shift0); o[6] = descale(t11 - a2, shift0);
+  o[2] = descale(t12 + a1, shift0); o[5] = descale(t12 - a1, shift0);
+  o[3] = descale(t13 + a0, shift0); o[4] = descale(t13 - a0, shift0);
+}
+
+// one 8x8 block: coefficients (natural order) x quantisation table -> 64 samples, row-major with `ld` bytes between rows
+HD void idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, long ld) {
+  int ws[64];
+  for (int c = 0; c < 8; ++c) {  // pass 1: columns (the all-AC-zero shortcut of the reference gives the same values)
+    int o[8];
+    idct_1d(coef[c] * q[c], coef[8 + c] * q[8 + c], coef[16 + c] * q[16 + c], coef[24 + c] * q[24 + c], coef[32 + c] * q[32 + c],
+            coef[40 + c] * q[40 + c], coef[48 + c] * q[48 + c], coef[56 + c] * q[56 + c], 13 - 2, o);
+    for (int r = 0; r < 8; ++r) ws[r * 8 + c] = o[r];
+  }
+  for (int r = 0; r < 8; ++r) {  // pass 2: rows
+    int o[8];
+    const int* w = ws + r * 8;
+    idct_1d(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], 13 + 2 + 3, o);
+    for (int c = 0; c < 8; ++c) out[r * ld + c] = idct_range_limit(o[c]);
+  }
+}
+
+struct Planes {
+  uint8_t* p[3];
+  int ld[3];       // bytes per plane row (blocks_w * 8)
+  int dsw[3], dsh[3];  // real (unpadded) extent of the component: ceil(image * samp / max)
+};
+
+// chroma sample at full-resolution position (X, Y): jdsample.c fullsize / h2v1 / h2v2, fancy (triangle) filters when the
+// downsampled width is > 2, plain replication otherwise
+HD int chroma_at(const uint8_t* pl, int ld, int dsw, int dsh, int hfac, int vfac, int X, int Y) {
+  if (hfac == 1 && vfac == 1) return pl[(long)Y * ld + X];
+  const int c = X >> 1;
+  if (vfac == 1) {  // h2v1
+    const uint8_t* row = pl + (long)Y * ld;
+    if (dsw <= 2) return row[c];
+    if (!(X & 1)) return c == 0 ? row[0] : (row[c] * 3 + row[c - 1] + 1) >> 2;
+    return c == dsw - 1 ? row[c] : (row[c] * 3 + row[c + 1] + 2) >> 2;
+  }
+  const int r = Y >> 1;  // h2v2
+  if (dsw <= 2) return pl[(long)r * ld + c];
+  int rn = (Y & 1) ? r + 1 : r - 1;  // nearer neighbour row; the first / last real row is its own neighbour at the image edge
+  rn = rn < 0 ? 0 : (rn > dsh - 1 ? dsh - 1 : rn);
+  const uint8_t* r0 = pl + (long)r * ld;
+  const uint8_t* r1 = pl + (long)rn * ld;
+  const int cur = r0[c] * 3 + r1[c];
+  if (!(X & 1)) {
+    if (c == 0) return (cur * 4 + 8) >> 4;
+    return (cur * 3 + (r0[c - 1] * 3 + r1[c - 1]) + 8) >> 4;
+  }
+  if (c == dsw - 1) return (cur * 4 + 7) >> 4;
+  return (cur * 3 + (r0[c + 1] * 3 + r1[c + 1]) + 7) >> 4;
+}
+
+HD uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// jdcolor.c ycc_rgb_convert: SCALEBITS 16 tables, evaluated directly
+HD void ycc_to_rgb(int y, int cb, int cr, uint8_t* o) {
+  const int xb = cb - 128, xr = cr - 128;
+  const int cr_r = (91881 * xr + 32768) >> 16;
+  const int cb_b = (116130 * xb + 32768) >> 16;
+  const int g = (-22554 * xb + 32768 + (-46802) * xr) >> 16;
+  o[0] = clamp255(y + cr_r);
+  o[1] = clamp255(y + g);
+  o[2] = clamp255(y + cb_b);
+}
+
+HD void pixel_rgb(const msocr_jpeg_info& f, const Planes& pl, int X, int Y, uint8_t* o) {
+  const int y = pl.p[0][(long)Y * pl.ld[0] + X];
+  if (f.ncomp == 1) {
+    o[0] = o[1] = o[2] = (uint8_t)y;
+    return;
+  }
+  const int cb = chroma_at(pl.p[1], pl.ld[1], pl.dsw[1], pl.dsh[1], f.hs[0], f.vs[0], X, Y);
+  const int cr = chroma_at(pl.p[2], pl.ld[2], pl.dsw[2], pl.dsh[2], f.hs[0], f.vs[0], X, Y);
+  ycc_to_rgb(y, cb, cr, o);
+}
+
+Planes make_planes(const msocr_jpeg_info& f, uint8_t* base) {
+  Planes pl;
+  int64_t off = 0;
+  for (int c = 0; c < 3; ++c) {
+    pl.p[c] = nullptr; pl.ld[c] = 0; pl.dsw[c] = 0; pl.dsh[c] = 0;
+    if (c < f.ncomp) {
+      pl.p[c] = base + off;
+      pl.ld[c] = f.blocks_w[c] * 8;
+      pl.dsw[c] = (f.width * f.hs[c] + f.hs[0] - 1) / f.hs[0];
+      pl.dsh[c] = (f.height * f.vs[c] + f.vs[0] - 1) / f.vs[0];
+      off += ((int64_t)f.blocks_w[c] * f.blocks_h[c] * 64 + 255) / 256 * 256;
+    }
+  }
+  return pl;
+}
+
+int64_t planes_bytes(const msocr_jpeg_info& f) {
+  int64_t off = 0;
+  for (int c = 0; c < f.ncomp; ++c) off += ((int64_t)f.blocks_w[c] * f.blocks_h[c] * 64 + 255) / 256 * 256;
+  return off;
+}
+
+bool info_ok(const msocr_jpeg_info* f) {
+  if (!f || f->supported != 1 || (f->ncomp != 1 && f->ncomp != 3) || f->width <= 0 || f->height <= 0) return false;
+  int64_t off = 0;
+  for (int c = 0; c < f->ncomp; ++c) {
+    if (f->hs[c] < 1 || f->hs[c] > 2 || f->vs[c] < 1 || f->vs[c] > 2 || f->blocks_w[c] <= 0 || f->blocks_h[c] <= 0) return false;
+    if (f->coef_off[c] != off) return false;
+    if ((int64_t)f->blocks_w[c] * 8 * f->hs[0] / f->hs[c] < f->width || (int64_t)f->blocks_h[c] * 8 * f->vs[0] / f->vs[c] < f->height) return false;
+    off += (int64_t)f->blocks_w[c] * f->blocks_h[c] * 64;
+  }
+  return off == f->coef_total;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(msocr_jpeg_info f, const int16_t* __restrict__ coef, Planes pl) {
+  const long nb0 = (long)f.blocks_w[0] * f.blocks_h[0];
+  const long nb1 = f.ncomp == 3 ? (long)f.blocks_w[1] * f.blocks_h[1] : 0;
+  const long total = nb0 + 2 * nb1;
+  for (long b = (long)blockIdx.x * 256 + threadIdx.x; b < total; b += (long)gridDim.x * 256) {
+    int c = 0;
+    long k = b;
+    if (k >= nb0) { k -= nb0; c = 1; if (k >= nb1) { k -= nb1; c = 2; } }
+    const int by = (int)(k / f.blocks_w[c]), bx = (int)(k - (long)by * f.blocks_w[c]);
+    idct_block(coef + f.coef_off[c] + k * 64, f.quant[c], pl.p[c] + ((long)by * 8) * pl.ld[c] + bx * 8, pl.ld[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(msocr_jpeg_info f, Planes pl, uint8_t* __restrict__ rgb) {
+  const long total = (long)f.width * f.height;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int Y = (int)(i / f.width), X = (int)(i - (long)Y * f.width);
+    uint8_t o[3];
+    pixel_rgb(f, pl, X, Y, o);
+    rgb[3 * i] = o[0]; rgb[3 * i + 1] = o[1]; rgb[3 * i + 2] = o[2];
+  }
+}
+
+}  // namespace
+
+extern "C" int msocr_jpeg_parse_host(const uint8_t* data_host, int64_t len, msocr_jpeg_info* info_out) {
+  if (!info_out) return MSOCR_E_ARG;
+  Parsed P;
+  const int rc = parse(data_host, len, &P);
+  *info_out = P.info;
+  if (rc != MSOCR_OK) info_out->supported = 0;
+  return rc;
+}
+
+extern "C" int msocr_jpeg_entropy_decode_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int16_t* coef_out_host) {
+  if (!coef_out_host || !info) return MSOCR_E_ARG;
+  Parsed P;
+  if (parse(data_host, len, &P) != MSOCR_OK) return MSOCR_E_ARG;
+  if (P.info.width != info->width || P.info.height != info->height || P.info.ncomp != info->ncomp ||
+      P.info.coef_total != info->coef_total) return MSOCR_E_ARG;  // `info` must be what parse returned for this stream
+  return entropy_decode(P, data_host + len, coef_out_host);
+}
+
+extern "C" int64_t msocr_jpeg_workspace_bytes(const msocr_jpeg_info* info) { return info_ok(info) ? planes_bytes(*info) : -1; }
+
+extern "C" int msocr_jpeg_reconstruct(const msocr_jpeg_info* info, const int16_t* coef_dev, void* workspace_dev, uint8_t* rgb_out_dev,
+                                      void* stream) {
+  if (!info_ok(info) || !coef_dev || !workspace_dev || !rgb_out_dev || ((uintptr_t)workspace_dev & 15)) return MSOCR_E_ARG;
+  const Planes pl = make_planes(*info, (uint8_t*)workspace_dev);
+  const long nblk = (long)info->coef_total / 64;
+  long g1 = (nblk + 255) / 256;
+  if (g1 > 65535) g1 = 65535;
+  MSOCR_LAUNCH(jpeg_idct_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, *info, coef_dev, pl);
+  if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+  long g2 = ((long)info->width * info->height + 255) / 256;
+  if (g2 > 65535) g2 = 65535;
+  MSOCR_LAUNCH(jpeg_color_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, *info, pl, rgb_out_dev);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_jpeg_reconstruct_host(const msocr_jpeg_info* info, const int16_t* coef_host, uint8_t* rgb_out_host) {
+  if (!info_ok(info) || !coef_host || !rgb_out_host) return MSOCR_E_ARG;
+  std::vector<uint8_t> ws((size_t)planes_bytes(*info));
+  const Planes pl = make_planes(*info, ws.data());
+  for (int c = 0; c < info->ncomp; ++c)
+    for (int by = 0; by < info->blocks_h[c]; ++by)
+      for (int bx = 0; bx < info->blocks_w[c]; ++bx)
+        idct_block(coef_host + info->coef_off[c] + ((int64_t)by * info->blocks_w[c] + bx) * 64, info->quant[c],
+                   pl.p[c] + ((long)by * 8) * pl.ld[c] + bx * 8, pl.ld[c]);
+  for (int Y = 0; Y < info->height; ++Y)
+    for (int X = 0; X < info->width; ++X) pixel_rgb(*info, pl, X, Y, rgb_out_host + 3 * ((int64_t)Y * info->width + X));
+  return MSOCR_OK;
+}

@@ -232,17 +232,30 @@ class EAST:
 
     def predict_batch(self, images: Sequence[np.ndarray], vis=False, profile=False, return_maps=False,
                       sort_reading_order=False, _maps_override=None, _pages_dev=None) -> List[Dict[str, Any]]:
-        imgs = [read_image(im) for im in images]
+        imgs, decoded = [], []
+        for im in images:
+            t = None
+            if _pages_dev is None and not vis and getattr(self, "device_ingest", True):
+                from ... import ingest
+                t = ingest.read_image_device(im, self.device)  # JPEG file: decoded on the device, the host keeps only the shape
+            imgs.append(np.broadcast_to(np.uint8(0), tuple(t.shape)) if t is not None else read_image(im))
+            decoded.append(t)
         if len({im.shape for im in imgs}) != 1:
             raise ValueError("predict_batch needs equally sized pages")
-        pages = _pages_dev if _pages_dev is not None else \
-            torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
+        if _pages_dev is not None:
+            pages = _pages_dev
+        elif all(t is not None for t in decoded):
+            pages = torch.stack(decoded)
+        else:
+            pages = torch.stack([t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+                                 for t, a in zip(decoded, imgs)])
         return self.detect_finish(self.detect_start(pages, _maps_override), imgs, vis, profile, return_maps, sort_reading_order)
 
     def predict(self, img_or_path: Union[str, Path, np.ndarray], vis: bool = False, profile: bool = False,
                 return_maps: bool = False, sort_reading_order: bool = False) -> Dict[str, Any]:
         """Same contract as the reference EAST.predict (infer.py:235-402): keys
         {"page","vis_image","score_map","geo_map"}; FileNotFoundError / TypeError on bad input."""
-        img = read_image(img_or_path)
-        return self.predict_batch([img], vis=vis, profile=profile, return_maps=return_maps,
+        if not isinstance(img_or_path, (str, Path, np.ndarray)):
+            raise TypeError(f"Unsupported type for image input: {type(img_or_path)}")  # read_image's contract (utils.py:494-495)
+        return self.predict_batch([img_or_path], vis=vis, profile=profile, return_maps=return_maps,
                                   sort_reading_order=sort_reading_order)[0]

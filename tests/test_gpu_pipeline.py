@@ -378,3 +378,54 @@ def test_predict_batch_device_order_equals_host_order(gpu):
     key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
     assert [key(p) for p in a] == [key(p) for p in b]
     assert sum(len(p.blocks[0].words) for p in a) > 60 and any(w.text for p in a for w in p.blocks[0].words)
+
+
+def test_device_jpeg_ingest(gpu, tmp_path):
+    """SURVEY.md 8f.2 image ingest: a JPEG page decoded on the device (host Huffman stage + HIP dequant / IDCT / upsample /
+    colour kernels) is bit-identical to PIL's decode (what the reference's read_image returns), for 4:2:0 / 4:2:2 / 4:4:4 and
+    grayscale files; Pipeline.predict(path) (device ingest) == Pipeline.predict(decoded array); progressive files and
+    missing files take the host path with the reference's errors."""
+    import io
+    from PIL import Image
+    from manuscript_ocr_amd import Pipeline, ingest, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    H, W = 256, 384
+    page = synth.synth_page(9, H, W)[0]
+    for kw in ({"subsampling": 2, "quality": 90}, {"subsampling": 1, "quality": 75}, {"subsampling": 0, "quality": 95}):
+        b = io.BytesIO()
+        Image.fromarray(page).save(b, format="JPEG", **kw)
+        exp = np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))
+        got = ingest.decode_jpeg_device(b.getvalue())
+        assert got is not None and np.array_equal(got.cpu().numpy(), exp), kw
+        assert np.array_equal(ingest.decode_jpeg_host(b.getvalue()), exp)
+    big = synth.synth_page(11, 1111, 1531)[0]  # partial MCUs, many blocks
+    b = io.BytesIO()
+    Image.fromarray(big).convert("L").save(b, format="JPEG", quality=85)
+    assert np.array_equal(ingest.decode_jpeg_device(b.getvalue()).cpu().numpy(), np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB")))
+    b = io.BytesIO()
+    Image.fromarray(big).save(b, format="JPEG", quality=88)
+    assert np.array_equal(ingest.decode_jpeg_device(b.getvalue()).cpu().numpy(), np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB")))
+    # through the plugin API
+    path = tmp_path / "page.jpg"
+    Image.fromarray(page).save(path, format="JPEG", quality=92)
+    prog = tmp_path / "prog.jpg"
+    Image.fromarray(page).save(prog, format="JPEG", quality=92, progressive=True)
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    det = EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda", score_thresh=0.5)
+    rec = TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda")
+    pipe = Pipeline(detector=det, recognizer=rec)
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    a = pipe.predict(str(path))
+    arr = np.array(Image.open(path).convert("RGB"))
+    assert key(a) == key(pipe.predict(arr)) and len(key(a)) > 0
+    pipe.device_ingest = False
+    assert key(a) == key(pipe.predict(str(path)))
+    pipe.device_ingest = True
+    assert key(pipe.predict(str(prog))) == key(pipe.predict(np.array(Image.open(prog).convert("RGB"))))
+    d1, d2 = det.predict(str(path)), det.predict(arr)
+    assert key(d1["page"]) == key(d2["page"])
+    with pytest.raises(FileNotFoundError):
+        pipe.predict(str(tmp_path / "missing.jpg"))
+    with pytest.raises(TypeError):
+        det.predict(12345)
