@@ -505,12 +505,14 @@ __device__ __forceinline__ bool merge_step(MergeState& st, const float* b, doubl
   return true;
 }
 
-__global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
+// TT threads per page (workspace carries are laid out for LANMS_T >= TT); REGNMS: keep the in-kernel register NMS loop
+template <int TT, bool REGNMS>
+__global__ __launch_bounds__(TT) void east_lanms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
                                                               int max_cand, double thr, float* __restrict__ boxes_out,
                                                               int32_t* __restrict__ nbox_out, char* __restrict__ ws, long ws_stride, long long* dbg,
                                                               long bits_off, int bitcap) {
   const int pg = blockIdx.x;
-  const int tid = threadIdx.x, nthr = LANMS_T;
+  const int tid = threadIdx.x, nthr = TT;
 #define DBG_STAMP(k) do { if (dbg && tid == 0) dbg[pg * 8 + (k)] = wall_clock64(); } while (0)
   DBG_STAMP(0);
   const float* cb = cand + (long)pg * max_cand * 9;
@@ -529,8 +531,8 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   int32_t* sbreak = flag + max_cand;
   float* ob = boxes_out + (long)pg * max_cand * 9;
   __shared__ int nm_s, nk_s, any_changed;
-  __shared__ int scan_s[LANMS_T / 64];
-  __shared__ unsigned char ch_s[LANMS_T];
+  __shared__ int scan_s[TT / 64];
+  __shared__ unsigned char ch_s[TT];
 
   int32_t* nm_hdr = reinterpret_cast<int32_t*>(w + bits_off);  // {merged polygons for the bit-matrix path, or -1}
   if (n == 0) {
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
   __syncthreads();
   int nk = 0;  // kept count (every thread tracks it; the owner of a kept polygon writes its row)
   constexpr int NQ = 4;
-  if (nm <= NQ * LANMS_T) {
+  if (REGNMS && nm <= NQ * TT) {
     // fast path: sorted position j = tid + q*1024 lives in thread tid's registers (polygon + suppressed flag); per
     // iteration the owner broadcasts polygon i through LDS (double-buffered: one barrier per iteration).
     __shared__ double bc_poly[2][8];
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
     bool sup[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int j = tid + q * LANMS_T;
+      const int j = tid + q * TT;
       sup[q] = true;
       ms_idx[q] = 0;
       if (j < nm) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
       }
     }
     for (int i = 0; i < nm; ++i) {
-      const int buf = i & 1, own = i % LANMS_T, oq = i / LANMS_T;
+      const int buf = i & 1, own = i % TT, oq = i / TT;
       if (tid == own) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(LANMS_T) void east_lanms_kernel(const float* __rest
       for (int k = 0; k < 8; ++k) a[k] = bc_poly[buf][k];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int j = tid + q * LANMS_T;
+        const int j = tid + q * TT;
         if (j > i && j < nm && !sup[q] && d_polygon_iou_q(a, mp[q]) > thr) sup[q] = true;
       }
     }
@@ -848,8 +850,26 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
   const int bits_on = getenv("MSOCR_LANMS_BITS") ? atoi(getenv("MSOCR_LANMS_BITS")) : 1;  // 0: greedy pass inside the page kernel (diagnostic)
   const long bits_off = lanms_bits_off(max_cand);
   const int bitcap = bits_on ? nms_bitcap(max_cand) : 0;
-  MSOCR_LAUNCH(east_lanms_kernel, dim3(N), dim3(LANMS_T), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out, nbox_out,
-                     (char*)workspace, stride, dbg, bits_off, bitcap);
+  // page kernel geometry: 768 threads = 3 waves per SIMD = 168 VGPRs per lane, enough for the register-resident polygon clip
+  // (at 1024 threads = 128 VGPRs it spills and the carry fix-up rounds get slower).  Measured on a 13 k-candidate page, phase 1 +
+  // score sort: 1024 threads with the old scratch-buffer clip 2.6 ms; 1024 / 768 / 512 / 256 threads with the register clip
+  // 2.3 / 1.7 / 2.1 / 2.7 ms.  MSOCR_LANMS_T=1024|1025|768|512|256 selects the others (diagnostics).
+  const int lt = getenv("MSOCR_LANMS_T") ? atoi(getenv("MSOCR_LANMS_T")) : 768;
+  if (lt == 1024)
+    MSOCR_LAUNCH((east_lanms_kernel<1024, true>), dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out,
+                 nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
+  else if (lt == 1025)
+    MSOCR_LAUNCH((east_lanms_kernel<1024, false>), dim3(N), dim3(1024), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out,
+                 nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
+  else if (lt == 768)
+    MSOCR_LAUNCH((east_lanms_kernel<768, false>), dim3(N), dim3(768), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out,
+                 nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
+  else if (lt == 256)
+    MSOCR_LAUNCH((east_lanms_kernel<256, false>), dim3(N), dim3(256), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out,
+                 nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
+  else
+    MSOCR_LAUNCH((east_lanms_kernel<512, false>), dim3(N), dim3(512), 0, (hipStream_t)stream, cand, counts, max_cand, iou_thr, boxes_out,
+                 nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
   int rc = LAUNCH_OK();
   if (rc == MSOCR_OK && bitcap > 0) {
     MSOCR_LAUNCH(lanms_iou_bits_kernel, dim3(64, N), dim3(256), 0, (hipStream_t)stream, (char*)workspace, stride, max_cand, iou_thr, bits_off,

@@ -234,6 +234,27 @@ def test_trba_random_weights_recorded_round1_case(env, mode):
     _assert_near_tie_parity(rep, 40, f"round-1 recorded case / {mode}")
 
 
+@pytest.mark.parametrize("mode", ["greedy", "beam"])
+def test_trba_shipped_config_32x128_maxlen40(env, mode):
+    """The configuration the reference ships (recognizers/_trba/configs/config.json: img_h 32, img_w 128, max_len 40,
+    hidden_size 256): T_enc = 17, 40 / 41 decode steps.  All-random weights, 96 crops, near-tie rule against the oracle."""
+    from conftest import compare_decodes, oracle_decode_chunks
+    from manuscript_ocr_amd.recognizers import TRBA
+    otm = env
+    N = 96
+    sd = synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED)
+    rec = TRBA(state_dict=sd, config={"img_h": 32, "img_w": 128, "max_len": 40, "hidden_size": 256}, device="cuda")
+    canv = synth.synth_crops(123, N, 32, 128)
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(sd, strict=True)
+    ref_net.eval()
+    exp = oracle_decode_chunks(ref_net, _x_from_canvases(canv), mode, max_len=40)
+    ids, trun, conf, lg = rec.recognize_canvases(torch.from_numpy(canv).cuda(), batch_size=32, mode=mode, return_logits=True)
+    assert ids.shape[1] == (41 if mode == "greedy" else 40)
+    rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=RANDOM_LOGIT_RTOL)
+    _assert_near_tie_parity(rep, N, f"shipped config 32x128 / max_len 40 / {mode}")
+
+
 def test_trba_random_weights_three_way(env, monkeypatch):
     """The same 256 all-random-weight crops through (a) the default path (Winograd 3x3 layers, matrix-core beam kernel),
     (b) direct convolutions only (MSOCR_WINOGRAD_MIN_CIN=0), (c) the VALU beam kernel (MSOCR_BEAM_MFMA=0): each against the
