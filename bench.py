@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--no-overlap-steps", action="store_true", help="do not enqueue step i+1's detector work before collecting step i")
     ap.add_argument("--sub-batches", type=int, default=0, help="sub-batch groups pipelined on separate streams (0 = auto)")
     ap.add_argument("--graphs", action="store_true",
-                    help="replay the detector's launch sequence from a hipGraph (measured 2 % slower than plain launches, DESIGN.md 7)")
+                    help="replay the detector's and the recogniser's launch sequences from hipGraphs (BASELINE configs[3] wording; "
+                         "DESIGN.md 7 has the A/B against plain launches)")
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the sub-batch pipeline on ONE stream (no cross-stream kernel overlap): per-kernel profiling mode")
     return ap.parse_args()
@@ -95,7 +96,7 @@ def main():
     esd = synth.east_state_dict(seed=20260128)
     tsd = synth.trba_state_dict_confident(194, 256, seed=20260128)
     det = EAST(state_dict=esd, target_size=(TW, TH), device="cuda", precision=a.precision, use_graphs=a.graphs)
-    rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision) if a.workload == "pipeline" else None
+    rec = TRBA(state_dict=tsd, config=TRBA_CFG, device="cuda", precision=a.precision, use_graphs=a.graphs) if a.workload == "pipeline" else None
     pipe = Pipeline(detector=det, recognizer=rec) if rec is not None else None
     if rec is not None and os.environ.get("MSOCR_DEVICE_BATCH"):
         rec.device_batch = int(os.environ["MSOCR_DEVICE_BATCH"])

@@ -293,16 +293,22 @@ class Pipeline:
                             off += c
                         if off:
                             spans = [tuple(sp) for sp in grp["spans"] if sp[1] > 0]
-                            with torch.cuda.stream(dst):  # the small blocking upload rides the high-priority stream
-                                prepared = rec.prepare_chunks(off, spans)
+                            use_graph = getattr(rec, "use_graphs", False)
+                            prepared = None
+                            if not use_graph:
+                                with torch.cuda.stream(dst):  # the small blocking upload rides the high-priority stream
+                                    prepared = rec.prepare_chunks(off, spans)
                             if st is not h["main"]:
                                 st.wait_stream(h["main"])  # the page upload
                             st.wait_stream(dst)
                             with torch.cuda.stream(st):
                                 ro[2].record_stream(st)
                                 desc_dev = torch.cat([ro[2][pi, :c] for pi, c in enumerate(nc_h.tolist()) if c])
-                                canv = ops.crop_resize_pad(pages_dev, None, rec.img_h, rec.img_w, desc_dev=desc_dev)
-                                grp["handle"] = rec.recognize_start(canv, spans=spans, prepared=prepared)
+                                if use_graph:  # crop + encode + decode as one hipGraph replay
+                                    grp["handle"] = rec.recognize_start_graph(pages_dev, desc_dev, spans, upload_stream=dst)
+                                if grp["handle"] is None:
+                                    canv = ops.crop_resize_pad(pages_dev, None, rec.img_h, rec.img_w, desc_dev=desc_dev)
+                                    grp["handle"] = rec.recognize_start(canv, spans=spans, prepared=prepared)
                         tm["crop+enqueue"] += time.perf_counter() - t0
                         groups.append(grp)
                         continue

@@ -36,6 +36,8 @@ class TRBA:
         state_dict = kwargs.pop("state_dict", None)
         config = kwargs.pop("config", None)
         self.device_batch = int(kwargs.pop("device_batch", 2048))
+        self.use_graphs = bool(kwargs.pop("use_graphs", False))  # hipGraph replay of crop + encode + beam decode (recognize_start_graph)
+        self._graphs: Dict[Any, Dict[str, Any]] = {}
         if kwargs:
             raise TypeError(f"Unexpected keyword argument(s): {', '.join(kwargs.keys())}")
         if weights_path is not None and model_path is not None:
@@ -200,6 +202,74 @@ class TRBA:
                                              self.blank_id, chunks))
         return {"parts": parts, "N": N, "mode": mode, "beam": beam_size, "bounds": bounds}
 
+    def recognize_start_graph(self, pages_dev: torch.Tensor, desc_dev: torch.Tensor, spans, batch_size=32, beam_size=8,
+                              temperature=1.7, alpha=0.9, upload_stream=None):
+        """`recognize_start` for crops that are still descriptors on the device (ops.reading_order_crops), as ONE hipGraph replay:
+        crop + ResizeAndPadA, SE-ResNet31, BiLSTMs and the beam decode of up to `device_batch` rows are captured once per
+        (page tensor, row bucket) and replayed (BASELINE configs[3]: "hipGraph-captured").  The row count is rounded up to a
+        multiple of 32; the padding rows repeat crop 0 and form a reference chunk of their own, so they can neither change a real
+        row's result nor delay a real chunk's early exit.  Falls back to the eager path (returns None) for empty or oversized
+        batches, while kernels are being profiled, and for the first call of a bucket (lazy one-time kernel attributes must not
+        fall into a capture).  Results are bit-identical to the eager path (tests/test_gpu_pipeline.py)."""
+        from ... import ops
+        M = int(desc_dev.shape[0])
+        Mcap = (M + 31) // 32 * 32
+        if M == 0 or Mcap > self.device_batch or ops.PROFILE is not None:
+            return None
+        nch_cap = Mcap // batch_size + len(spans) + 2  # chunks of the real rows (<= rows/batch_size + one per page) + the padding chunk
+        key = (pages_dev.data_ptr(), tuple(pages_dev.shape), Mcap, nch_cap, batch_size, beam_size, float(temperature), float(alpha))
+        pool = self._graphs.setdefault(key, {"warm": False, "inst": []})
+        if not pool["warm"]:
+            pool["warm"] = True
+            return None
+        # chunk metadata of the real rows (as prepare_chunks) + one chunk for the padding rows, into the instance's static buffer
+        bounds, metas = self._device_batches(M, spans, batch_size)
+        if metas is None or len(bounds) != 1:
+            return None
+        ids, sizes = metas[0][:M], metas[0][M:]
+        if len(sizes) + 1 > nch_cap:
+            return None
+        meta = np.zeros(Mcap + nch_cap, dtype=np.int32)
+        meta[:M] = ids
+        meta[M:Mcap] = len(sizes)
+        meta[Mcap:Mcap + len(sizes)] = sizes
+        meta[Mcap + len(sizes)] = max(Mcap - M, 1)
+        inst = next((i for i in pool["inst"] if not i["busy"]), None)
+        if inst is None:
+            if len(pool["inst"]) >= 4:
+                return None
+            for _ in range(2 if not pool["inst"] else 1):  # consecutive batches overlap: two instances per bucket
+                dbuf = torch.zeros((Mcap, 8), dtype=torch.int32, device=self.device)
+                mbuf = torch.zeros((Mcap + nch_cap,), dtype=torch.int32, device=self.device)
+                dbuf[:M].copy_(desc_dev)
+                dbuf[M:] = desc_dev[0]
+                mbuf.copy_(torch.from_numpy(meta).to(self.device))
+                torch.cuda.current_stream().synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    canv = ops.crop_resize_pad(pages_dev, None, self.img_h, self.img_w, desc_dev=dbuf)
+                    state = torch.zeros((2 * nch_cap,), dtype=torch.int32, device=self.device)
+                    batch_H, proj_H = self.model.encode(canv)
+                    part = self.model.beam(batch_H, proj_H, self.max_length, beam_size, alpha, temperature, self.sos_id, self.eos_id,
+                                           self.blank_id, (mbuf[:Mcap], mbuf[Mcap:], state))
+                pool["inst"].append({"graph": graph, "desc": dbuf, "meta": mbuf, "part": part, "busy": False})
+            inst = pool["inst"][-1]
+        inst["busy"] = True
+        inst["desc"][:M].copy_(desc_dev, non_blocking=True)
+        if Mcap > M:
+            inst["desc"][M:] = desc_dev[0]
+        # the small blocking upload of the chunk metadata must not queue behind the recogniser work already on this stream
+        cur = torch.cuda.current_stream()
+        up = upload_stream if upload_stream is not None else cur
+        with torch.cuda.stream(up):
+            meta_dev = torch.from_numpy(meta).to(self.device)
+        if up is not cur:
+            cur.wait_stream(up)
+            meta_dev.record_stream(cur)
+        inst["meta"].copy_(meta_dev, non_blocking=True)
+        inst["graph"].replay()
+        return {"parts": [inst["part"]], "N": Mcap, "M_real": M, "mode": "beam", "beam": beam_size, "bounds": [(0, Mcap)], "graph_inst": inst}
+
     def recognize_finish(self, handle, batch_size=32, spans=None, return_logits=False):
         """Phases 2-3 — derive the reference's per-chunk run lengths, back-track (beam) and reduce confidences.
 
@@ -210,9 +280,10 @@ class TRBA:
         from ... import _native as nat
         from ... import ops
         parts, N, mode, beam_size = handle["parts"], handle["N"], handle["mode"], handle["beam"]
-        spans = spans if spans is not None else [(0, N)]
+        M_real = handle.get("M_real", N)  # a graph replay carries padding rows behind the real ones
+        spans = spans if spans is not None else [(0, M_real)]
         steps = self.max_length + 1 if mode == "greedy" else self.max_length
-        trun = np.empty(N, dtype=np.int32)
+        trun = np.ones(N, dtype=np.int32)
         if mode == "greedy":
             ids_h = np.concatenate([p[1].cpu().numpy() for p in parts])
             for s0, cnt in spans:
@@ -226,7 +297,8 @@ class TRBA:
                 for c0 in range(s0, s0 + cnt, batch_size):
                     c1 = min(c0 + batch_size, s0 + cnt)
                     trun[c0:c1] = fin_h[c0:c1].max()
-        self.last_run_length_sum, self.last_rows = getattr(self, "last_run_length_sum", 0) + int(trun.sum()), getattr(self, "last_rows", 0) + N
+        self.last_run_length_sum = getattr(self, "last_run_length_sum", 0) + int(trun[:M_real].sum())
+        self.last_rows = getattr(self, "last_rows", 0) + M_real
         trun_dev = torch.from_numpy(trun).to(self.device)
         ids_out, conf_out, logit_out = [], [], []
         for k, (s, hi) in enumerate(handle["bounds"]):
@@ -243,11 +315,13 @@ class TRBA:
             if return_logits:
                 logit_out.append(lg.cpu().numpy())
             parts[k] = None
-        ids_h = torch.cat(ids_out).cpu().numpy()
-        conf_h = torch.cat(conf_out).cpu().numpy()
+        ids_h = torch.cat(ids_out).cpu().numpy()[:M_real]
+        conf_h = torch.cat(conf_out).cpu().numpy()[:M_real]
+        if handle.get("graph_inst") is not None:
+            handle["graph_inst"]["busy"] = False  # every output of the graph instance has been read back
         if return_logits:
-            return ids_h, trun, conf_h, np.concatenate(logit_out)
-        return ids_h, trun, conf_h
+            return ids_h, trun[:M_real], conf_h, np.concatenate(logit_out)[:M_real]
+        return ids_h, trun[:M_real], conf_h
 
     def recognize_canvases(self, canvases_dev: torch.Tensor, batch_size=32, mode="beam", beam_size=8, temperature=1.7, alpha=0.9,
                            spans=None, return_logits=False):

@@ -429,3 +429,43 @@ def test_device_jpeg_ingest(gpu, tmp_path):
         pipe.predict(str(tmp_path / "missing.jpg"))
     with pytest.raises(TypeError):
         det.predict(12345)
+
+
+def test_whole_pipeline_hipgraph_replay_equals_eager(gpu):
+    """BASELINE configs[3] "hipGraph-captured": EAST(use_graphs=True) + TRBA(use_graphs=True) — detector (resize, network, decode,
+    LANMS, box filters) and recogniser (device crops, SE-ResNet31, BiLSTMs, beam decode) each replayed from a hipGraph — return
+    the same Pages as plain launches, call after call (first call of a shape runs eagerly, the second captures, later ones replay),
+    also when the number of crops changes between calls (row buckets of 32 with a padding chunk)."""
+    from manuscript_ocr_amd import Pipeline, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    H, W = 512, 768
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    esd, tsd = synth.east_state_dict(), synth.trba_state_dict_confident(194, 256, seed=3)
+    eager = Pipeline(EAST(state_dict=esd, target_size=(W, H), device="cuda"), TRBA(state_dict=tsd, config=cfg, device="cuda"))
+    graph = Pipeline(EAST(state_dict=esd, target_size=(W, H), device="cuda", use_graphs=True),
+                     TRBA(state_dict=tsd, config=cfg, device="cuda", use_graphs=True))
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    sets = []
+    for seeds, kw in (((61, 62), {}), ((63, 64), {}), ((65, 66), {"line_pitch": 48})):
+        pages, maps = [], []
+        for seed in seeds:
+            pg, rects = synth.synth_page(seed, H, W, **kw)
+            pages.append(pg)
+            maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+        sets.append((pages, (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())))
+    # static page / map tensors, like a serving loop that reuses its input buffers: graphs are keyed by the page tensor
+    pages_dev = torch.empty((2, H, W, 3), dtype=torch.uint8, device="cuda")
+    mo = (torch.empty_like(sets[0][1][0]), torch.empty_like(sets[0][1][1]))
+    counts = []
+    for rnd in range(3):
+        for pages, m in sets:
+            pages_dev.copy_(torch.from_numpy(np.stack(pages)))
+            mo[0].copy_(m[0]), mo[1].copy_(m[1])
+            a = eager.predict_batch(pages, pages_dev=pages_dev, _maps_override=mo)
+            b = graph.predict_batch(pages, pages_dev=pages_dev, _maps_override=mo)
+            assert [key(p) for p in a] == [key(p) for p in b], rnd
+            counts.append(sum(w.text is not None for p in a for w in p.blocks[0].words))
+    assert len(set(counts)) >= 2 and min(counts) > 20
+    assert any(pool["inst"] for pool in graph.recognizer._graphs.values()), "the recogniser never replayed a graph"
+    assert any(pool["inst"] for pool in graph.detector._graphs.values())
