@@ -242,6 +242,7 @@ def main():
         },
     }
 
+    res["max_memory_reserved_gb"] = round(torch.cuda.max_memory_reserved() / 2 ** 30, 2)  # after the timed steps (allocator high-water)
     if pipe is not None:
         res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}
         res["east_stage_s_last_step"] = {k: round(v, 4) for k, v in det.last_profile.items()}
@@ -363,7 +364,6 @@ def main():
                 for tag, (cnt, m, f, fe) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     fh.write(f"M={tag[0]} N={tag[1]} K={tag[2]} {tag[3]} calls_per_step={cnt / a.steps:g} ms_per_step={m / a.steps:.3f} "
                              f"alg_TF/s={f / (m * 1e-3) / 1e12:.1f} executed_TF/s={fe / (m * 1e-3) / 1e12:.1f}\n")
-        res["max_memory_reserved_gb"] = torch.cuda.max_memory_reserved() / 2 ** 30
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out, target_wh=(TW, TH))

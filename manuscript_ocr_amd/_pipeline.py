@@ -307,6 +307,10 @@ class Pipeline:
                                 if use_graph:  # crop + encode + decode as one hipGraph replay
                                     grp["handle"] = rec.recognize_start_graph(pages_dev, desc_dev, spans, upload_stream=dst)
                                 if grp["handle"] is None:
+                                    if prepared is None:  # graph path declined (first call of a bucket, ...): plain launches
+                                        with torch.cuda.stream(dst):
+                                            prepared = rec.prepare_chunks(off, spans)
+                                        st.wait_stream(dst)
                                     canv = ops.crop_resize_pad(pages_dev, None, rec.img_h, rec.img_w, desc_dev=desc_dev)
                                     grp["handle"] = rec.recognize_start(canv, spans=spans, prepared=prepared)
                         tm["crop+enqueue"] += time.perf_counter() - t0

@@ -217,7 +217,9 @@ class TRBA:
         if M == 0 or Mcap > self.device_batch or ops.PROFILE is not None:
             return None
         nch_cap = Mcap // batch_size + len(spans) + 2  # chunks of the real rows (<= rows/batch_size + one per page) + the padding chunk
-        key = (pages_dev.data_ptr(), tuple(pages_dev.shape), Mcap, nch_cap, batch_size, beam_size, float(temperature), float(alpha))
+        # one pool per launch stream: the groups of a batch are in flight together, each replays its own instances
+        key = (torch.cuda.current_stream().cuda_stream, pages_dev.data_ptr(), tuple(pages_dev.shape), Mcap, nch_cap, batch_size, beam_size,
+               float(temperature), float(alpha))
         pool = self._graphs.setdefault(key, {"warm": False, "inst": []})
         if not pool["warm"]:
             pool["warm"] = True
