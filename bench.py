@@ -164,14 +164,33 @@ def main():
             for _ in range(k):
                 out_ = step()
             return out_
-        depth = int(os.environ.get("MSOCR_PIPE_DEPTH", "1"))  # batches advanced ahead of the one being collected
-        pipe.stream_sets = depth + 1
-        queue, out_, nsub = [], None, 0
+        if os.environ.get("MSOCR_PIPE_DEPTH"):  # diagnostic: the round-1 schedule (advance `depth` batches ahead, then collect)
+            depth = int(os.environ["MSOCR_PIPE_DEPTH"])
+            pipe.stream_sets = depth + 1  # an upper bound: the pipeline drops to one set when two would not fit the HBM
+            queue, out_, nsub = [], None, 0
+            for i in range(k):
+                while nsub < k and len(queue) <= depth:
+                    queue.append(pipe.advance_batch(submit()))
+                    nsub += 1
+                out_ = pipe.collect_batch(queue.pop(0))
+            return out_
+        # Schedule: while the host assembles the Pages of batch i (collect: ~0.1 s of Python), the device must already hold the
+        # detector work of batch i+2 — the recognisers of batches i and i+1 share the chip (two stream sets, equal priority) and
+        # finish almost together, so submitting D(i+2) only after collect(i) left the device idle for 7-18 ms per step (kernel
+        # trace, profiles/README.md).  Invariant at the top of the loop: batch i is advanced (recogniser enqueued), batch i+1 is
+        # submitted (detector enqueued).
+        pipe.stream_sets = 2
+        h_adv = pipe.advance_batch(submit())
+        h_sub = submit() if k > 1 else None
+        nsub, out_ = 2 if k > 1 else 1, None
         for i in range(k):
-            while nsub < k and len(queue) <= depth:
-                queue.append(pipe.advance_batch(submit()))
+            h_next = pipe.advance_batch(h_sub) if h_sub is not None else None   # waits for D(i+1)'s counts, enqueues R(i+1)
+            h_sub = None
+            if nsub < k:
+                h_sub = submit()                                               # D(i+2) goes to the device BEFORE the host stage
                 nsub += 1
-            out_ = pipe.collect_batch(queue.pop(0))
+            out_ = pipe.collect_batch(h_adv)                                    # waits for R(i), assembles the Pages
+            h_adv = h_next
             if STEP_TIMES is not None:
                 STEP_TIMES.append(time.perf_counter())
         return out_

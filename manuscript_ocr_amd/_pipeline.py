@@ -229,7 +229,15 @@ class Pipeline:
             # before it can enqueue the long recogniser tail: with equal priorities the detector kernels of batch i+1 share the
             # chip fairly with the recogniser of batch i and finish together with it, so the next recogniser work is enqueued
             # only when the device has already drained (measured: 5 % idle); at high priority they overtake it.
-            nsets = max(2, int(getattr(self, "stream_sets", 2)))  # batches that may be in flight at once
+            nsets = max(1, int(getattr(self, "stream_sets", 2)))  # batches that may be in flight at once
+            # Every stream keeps its own allocator pool (stream-ordered reuse without waiting for the device), so reserved memory
+            # grows with the number of streams in flight x the per-page activation footprint: measured 96 GB at 16 pages x
+            # 1536 x 2048 with two stream sets = 1.9 KB per page pixel.  When two sets would not fit comfortably (configs[4]:
+            # 16 pages x 3072 x 4096 -> 380 GB) consecutive batches share ONE set of streams: half the memory, still
+            # stream-ordered, a little less overlap between batches — instead of an allocator that thrashes at the 288 GB limit.
+            H_, W_ = arrays[0].shape[:2]
+            if nsets > 1 and 1900.0 * N * H_ * W_ > 0.6 * torch.cuda.get_device_properties(pages_dev.device).total_memory:
+                nsets = 1
             if not hasattr(self, "_stream_sets") or len(self._stream_sets) != nsets:
                 self._stream_sets, self._det_stream_sets, self._set_idx = [[] for _ in range(nsets)], [[] for _ in range(nsets)], 0
             self._set_idx = (self._set_idx + 1) % nsets

@@ -1,8 +1,10 @@
 """Where the device is idle or runs no convolution kernel: digest of a rocprofv3 --kernel-trace CSV (dev tool, CPU).
 
-    python tools/trace_gaps.py gpurun_out/<run>/<host>/<pid>_kernel_trace.csv [last_fraction]
+    python tools/trace_gaps.py gpurun_out/<run>/<host>/<pid>_kernel_trace.csv [first_step last_step total_steps]
 
-Takes the last `last_fraction` (default 0.4) of the trace (the timed steps of bench.py), merges the kernel intervals and prints:
+Takes the dispatches of steps [first_step, last_step) out of total_steps equally long (in dispatch count) steps — the default
+bench runs 2 priming + 2 warm-up + 5 timed + 6 instrumented + 6 serialized steps = 21, so "4 9 21" is the timed region — merges
+the kernel intervals and prints:
 busy fraction, time with no conv-stage kernel running, and the largest idle gaps with the kernels that end before / start after
 them."""
 import csv
@@ -29,14 +31,13 @@ def union(iv):
 
 def main():
     path = sys.argv[1]
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+    a, b, tot = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (4, 9, 21)
     rows = []
     for r in csv.DictReader(open(path)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+        rows.append((int(r["Dispatch_Id"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    t0, t1 = rows[0][0], max(r[1] for r in rows)
-    lo = t1 - int((t1 - t0) * frac)
-    rows = [r for r in rows if r[0] >= lo]
+    n = len(rows)
+    rows = sorted((s, e, k) for _, s, e, k in rows[n * a // tot: n * b // tot])
     span = (max(r[1] for r in rows) - rows[0][0]) / 1e6
     allu = union([(s, e) for s, e, _ in rows])
     convu = union([(s, e) for s, e, n in rows if n.startswith(CONV)])
