@@ -91,6 +91,10 @@ def _wino_workspace(nbytes, device):
     return buf
 
 
+# Winograd layers whose shape the row-split form supports (Cout % 128 == 0) take it when WINOGRAD_ROW_SPLIT is on
+WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "1"))
+
+
 def attach_winograd(w):
     """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twin U = G g G^T ([16,Cout,Cin] f32, computed
     on the host in f64 by msocr_winograd_weights_host).  conv2d() then takes the Winograd path for 3x3/1/1 calls."""
@@ -141,30 +145,39 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     bp = bias.data_ptr() if bias is not None else None
     alg = 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin)  # ALGORITHMIC direct-convolution FLOP (2 * MACs)
     if use_wino:
-        nbytes = nat.lib().msocr_conv3x3_winograd_workspace_bytes(ctypes.byref(d))
+        L = nat.lib()
+        rs = bool(WINOGRAD_ROW_SPLIT) and Cout % 128 == 0
+        nbytes = (L.msocr_conv3x3_winograd_rs_workspace_bytes if rs else L.msocr_conv3x3_winograd_workspace_bytes)(ctypes.byref(d))
         if nbytes < 0:
             raise nat.NativeError(f"winograd: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")
         parts = min(N, -(-nbytes // WINO_WS_LIMIT))  # images per call such that the workspace stays under the limit
         per = -(-N // parts)
         ws = _wino_workspace(nbytes if parts == 1 else (nbytes // N) * per, x.device)
-        what = f"msocr_conv3x3_winograd {tuple(x.shape)} * {tuple(w.shape)}"
+        what = f"msocr_conv3x3_winograd{'_rs' if rs else ''} {tuple(x.shape)} * {tuple(w.shape)}"
+        whole = L.msocr_conv3x3_winograd_rs if rs else L.msocr_conv3x3_winograd
+        st_in = L.msocr_winograd_rs_rows_in if rs else L.msocr_winograd_input_transform
+        st_gemm = L.msocr_winograd_rs_gemm if rs else L.msocr_winograd_gemm
+        st_out = L.msocr_winograd_rs_rows_out if rs else L.msocr_winograd_output_transform
+        TH, TW = (Ho + 1) // 2, (Wo + 1) // 2
         for n0 in range(0, N, per):
             n1 = min(N, n0 + per)
             d.N = n1 - n0
             xp, rp_, op = x[n0:n1].data_ptr(), (residual[n0:n1].data_ptr() if residual is not None else None), out[n0:n1].data_ptr()
             if prof is None:
-                nat.check(nat.lib().msocr_conv3x3_winograd(ctypes.byref(d), xp, u.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
+                nat.check(whole(ctypes.byref(d), xp, u.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
             else:  # the same three kernels through the per-stage entry points, one event pair each
-                nn, mt = n1 - n0, (n1 - n0) * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+                nn, mt = n1 - n0, (n1 - n0) * TH * TW
+                v_el = 4 * nn * TH * (2 * TW + 2) * Cin if rs else 16 * mt * Cin  # transformed input array (Q or V), elements
+                m_el = (8 if rs else 16) * mt * Cout                              # transformed output array (R or Mw)
                 e = _prof_begin()
-                nat.check(nat.lib().msocr_winograd_input_transform(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
-                _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + 16 * mt * Cin), (mt, Cin))
+                nat.check(st_in(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
+                _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + v_el), (mt, Cin))
                 e = _prof_begin()
-                nat.check(nat.lib().msocr_winograd_gemm(ctypes.byref(d), u.data_ptr(), ws.data_ptr(), _stream()), what)
+                nat.check(st_gemm(ctypes.byref(d), u.data_ptr(), ws.data_ptr(), _stream()), what)
                 _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 16 * mt * Cin * Cout), (nn * Ho * Wo, Cout, KH * KW * Cin, "winograd"))
                 e = _prof_begin()
-                nat.check(nat.lib().msocr_winograd_output_transform(ctypes.byref(d), ws.data_ptr(), bp, rp_, op, _stream()), what)
-                _prof_end(e, "wino_out", 4.0 * (16 * mt * Cout + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))
+                nat.check(st_out(ctypes.byref(d), ws.data_ptr(), bp, rp_, op, _stream()), what)
+                _prof_end(e, "wino_out", 4.0 * (m_el + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))
         d.N = N
     else:
         e = _prof_begin()

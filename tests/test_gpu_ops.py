@@ -78,13 +78,17 @@ WINO_CASES = [
     (1, 17, 23, 128, 64, False, False),
     (2, 1, 7, 128, 128, True, True),
     (1, 32, 48, 256, 128, False, True),
+    (5, 7, 9, 128, 384, True, True),   # odd x odd map, 3 cout blocks, tiles not a multiple of the 64-tile workgroup
 ]
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv3x3_winograd_vs_direct_and_f64(ops, case):
+@pytest.mark.parametrize("row_split", [1, 0])
+def test_conv3x3_winograd_vs_direct_and_f64(ops, case, row_split, monkeypatch):
     """Winograd F(2x2,3x3) path (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as
-    the direct kernel, and its error stays within 4x of the direct kernel's own error against f64 (rounding order only)."""
+    the direct kernel, and its error stays within 4x of the direct kernel's own error against f64 (rounding order only).
+    row_split = 1: the axis-split form (csrc/winograd_rs.hip, Cout % 128 == 0) ; 0: the plain V / Mw form (csrc/winograd.hip)."""
+    monkeypatch.setattr(ops, "WINOGRAD_ROW_SPLIT", row_split)
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]))
     x = torch.randn(N, Cin, H, W, generator=g)
