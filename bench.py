@@ -180,17 +180,19 @@ def main():
         # trace, profiles/README.md).  Invariant at the top of the loop: batch i is advanced (recogniser enqueued), batch i+1 is
         # submitted (detector enqueued).
         pipe.stream_sets = 2
-        h_adv = pipe.advance_batch(submit())
-        h_sub = submit() if k > 1 else None
-        nsub, out_ = 2 if k > 1 else 1, None
+        ahead = int(os.environ.get("MSOCR_SCHED_AHEAD", "1"))  # batches whose recogniser is enqueued ahead of the one being collected
+        adv, sub, nsub, out_ = [], [], 0, None
         for i in range(k):
-            h_next = pipe.advance_batch(h_sub) if h_sub is not None else None   # waits for D(i+1)'s counts, enqueues R(i+1)
-            h_sub = None
-            if nsub < k:
-                h_sub = submit()                                               # D(i+2) goes to the device BEFORE the host stage
-                nsub += 1
-            out_ = pipe.collect_batch(h_adv)                                    # waits for R(i), assembles the Pages
-            h_adv = h_next
+            # top up: `ahead` + 1 batches advanced (recogniser enqueued), one more submitted (detector enqueued)
+            while len(adv) < ahead + 1 and (sub or nsub < k):
+                if not sub:
+                    sub.append(submit())
+                    nsub += 1
+                adv.append(pipe.advance_batch(sub.pop(0)))        # waits for D's crop counts, enqueues R
+                if nsub < k:
+                    sub.append(submit())                          # the next detector goes to the device BEFORE the host stage
+                    nsub += 1
+            out_ = pipe.collect_batch(adv.pop(0))                 # waits for R(i), assembles the Pages
             if STEP_TIMES is not None:
                 STEP_TIMES.append(time.perf_counter())
         return out_

@@ -91,7 +91,9 @@ def _wino_workspace(nbytes, device):
     return buf
 
 
-# Winograd layers whose shape the row-split form supports (Cout % 128 == 0) take it when WINOGRAD_ROW_SPLIT is on
+# Row-split Winograd form (csrc/winograd_rs.hip: half the transform traffic, a 4-point GEMM at 2 workgroups per CU).  Measured
+# per layer (tools/conv_bench.py): Cin = 256 layers 6-9 % faster than the plain form, Cin = 512 layers 2 % slower (the GEMM's lower
+# occupancy costs more than the transforms save), so: 1 = layers with Cin <= 256 (default), 2 = every supported layer, 0 = off.
 WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "1"))
 
 
@@ -146,7 +148,7 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     alg = 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin)  # ALGORITHMIC direct-convolution FLOP (2 * MACs)
     if use_wino:
         L = nat.lib()
-        rs = bool(WINOGRAD_ROW_SPLIT) and Cout % 128 == 0
+        rs = Cout % 128 == 0 and (WINOGRAD_ROW_SPLIT >= 2 or (WINOGRAD_ROW_SPLIT == 1 and Cin <= 256))
         nbytes = (L.msocr_conv3x3_winograd_rs_workspace_bytes if rs else L.msocr_conv3x3_winograd_workspace_bytes)(ctypes.byref(d))
         if nbytes < 0:
             raise nat.NativeError(f"winograd: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")

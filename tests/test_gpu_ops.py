@@ -83,11 +83,11 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
-@pytest.mark.parametrize("row_split", [1, 0])
+@pytest.mark.parametrize("row_split", [2, 0])
 def test_conv3x3_winograd_vs_direct_and_f64(ops, case, row_split, monkeypatch):
     """Winograd F(2x2,3x3) path (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as
     the direct kernel, and its error stays within 4x of the direct kernel's own error against f64 (rounding order only).
-    row_split = 1: the axis-split form (csrc/winograd_rs.hip, Cout % 128 == 0) ; 0: the plain V / Mw form (csrc/winograd.hip)."""
+    row_split = 2: the axis-split form on every layer it supports (csrc/winograd_rs.hip, Cout % 128 == 0) ; 0: the plain V / Mw form (csrc/winograd.hip)."""
     monkeypatch.setattr(ops, "WINOGRAD_ROW_SPLIT", row_split)
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]))

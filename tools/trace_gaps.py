@@ -15,7 +15,7 @@ CONV = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel")
 
 
 def short(n):
-    return n.replace("void ", "").split("(")[0].replace("(anonymous namespace)::", "")[:60]
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
 
 
 def union(iv):
