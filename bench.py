@@ -182,19 +182,27 @@ def main():
         pipe.stream_sets = 2
         ahead = int(os.environ.get("MSOCR_SCHED_AHEAD", "1"))  # batches whose recogniser is enqueued ahead of the one being collected
         adv, sub, nsub, out_ = [], [], 0, None
+        ph = STEP_TIMES  # diagnostics (MSOCR_STEP_TIMES): host time of every phase
         for i in range(k):
             # top up: `ahead` + 1 batches advanced (recogniser enqueued), one more submitted (detector enqueued)
             while len(adv) < ahead + 1 and (sub or nsub < k):
                 if not sub:
                     sub.append(submit())
                     nsub += 1
+                t_ = time.perf_counter()
                 adv.append(pipe.advance_batch(sub.pop(0)))        # waits for D's crop counts, enqueues R
+                if ph is not None:
+                    ph.append(("advance", t_, time.perf_counter()))
                 if nsub < k:
+                    t_ = time.perf_counter()
                     sub.append(submit())                          # the next detector goes to the device BEFORE the host stage
                     nsub += 1
+                    if ph is not None:
+                        ph.append(("submit", t_, time.perf_counter()))
+            t_ = time.perf_counter()
             out_ = pipe.collect_batch(adv.pop(0))                 # waits for R(i), assembles the Pages
-            if STEP_TIMES is not None:
-                STEP_TIMES.append(time.perf_counter())
+            if ph is not None:
+                ph.append(("collect", t_, time.perf_counter(), dict(pipe.last_profile)))
         return out_
 
     def barrier():
@@ -390,7 +398,10 @@ def main():
         res["cpu_baseline"] = cpu_baseline(a.workload, esd, tsd, pages, scores, geos, H, W, out, target_wh=(TW, TH))
 
     if STEP_TIMES:
-        print("step end times (s):", [round(t - STEP_TIMES[0], 3) for t in STEP_TIMES], file=sys.stderr)
+        t00 = STEP_TIMES[0][1]
+        for rec_ in STEP_TIMES:
+            print(f"[phase] {rec_[0]:8s} {1e3 * (rec_[1] - t00):9.1f} .. {1e3 * (rec_[2] - t00):9.1f} ms  ({1e3 * (rec_[2] - rec_[1]):6.1f})"
+                  + (f"  {rec_[3]}" if len(rec_) > 3 else ""), file=sys.stderr)
     if rank == 0:
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:

@@ -248,7 +248,7 @@ class Pipeline:
                 dpool.append(torch.cuda.Stream(priority=hi_prio))
             streams, det_streams = pool[:nsub], dpool[:nsub]
         from . import ops
-        det_handles, ro_handles = [], []
+        det_handles, ro_handles, det_events = [], [], []
         H, W = arrays[0].shape[:2]
         for (lo, hi), st in zip(bounds, det_streams):
             if st is not main:
@@ -264,8 +264,11 @@ class Pipeline:
                     ro = ops.reading_order_crops(dh[5], dh[6], (H, W), self.min_text_size, self.recognizer.img_h, self.recognizer.img_w,
                                                  page_base=lo)
                 ro_handles.append(ro)
+                ev = torch.cuda.Event()
+                ev.record(st)  # detector outputs of this group complete
+                det_events.append(ev)
         return {"arrays": arrays, "pages_dev": pages_dev, "bounds": bounds, "streams": streams, "det_streams": det_streams, "main": main,
-                "det_handles": det_handles, "ro_handles": ro_handles, "recognize_text": recognize_text, "profile": profile}
+                "det_handles": det_handles, "ro_handles": ro_handles, "det_events": det_events, "recognize_text": recognize_text, "profile": profile}
 
     def advance_batch(self, h):
         """Stage 2 of `predict_batch` for a handle from `submit_batch`: per group — wait for its boxes, run the host
@@ -285,7 +288,7 @@ class Pipeline:
         H, W = arrays[0].shape[:2]
         pages, groups = [None] * N, []
         with _gc_paused():
-            for (lo, hi), st, dst, dh, ro in zip(bounds, streams, h["det_streams"], h["det_handles"], h["ro_handles"]):
+            for (lo, hi), st, dst, dh, ro, dev_ev in zip(bounds, streams, h["det_streams"], h["det_handles"], h["ro_handles"], h["det_events"]):
                 if ro is not None:
                     # device path: wait for the group's crop counts only (4 bytes per page), enqueue crops + recogniser
                     with torch.cuda.stream(dst):
@@ -294,7 +297,7 @@ class Pipeline:
                         tm["detect_wait+tail"] += time.perf_counter() - t0
                     if bool((nc_h >= 0).all()):
                         t0 = time.perf_counter()
-                        grp = {"words": None, "spans": [], "handle": None, "ro": ro, "det": dh, "lohi": (lo, hi), "dst": dst}
+                        grp = {"words": None, "spans": [], "handle": None, "ro": ro, "det": dh, "lohi": (lo, hi), "dst": dst, "det_event": dev_ev}
                         off = 0
                         for c in nc_h.tolist():
                             grp["spans"].append([off, c])
@@ -387,7 +390,13 @@ class Pipeline:
                 if grp.get("ro") is not None:
                     # device-ordered group: Page / Word assembly happens here, off the path that feeds the device
                     lo, hi = grp["lohi"]
-                    with torch.cuda.stream(grp["dst"]):
+                    # read the boxes back on a copy stream of their own that only waits for the group's detector outputs: on the
+                    # detector stream these copies would queue behind the detector work of the batch after next (it shares that
+                    # stream), on the recogniser stream behind this batch's whole recogniser
+                    if not hasattr(self, "_copy_stream"):
+                        self._copy_stream = torch.cuda.Stream(priority=-1)
+                    self._copy_stream.wait_event(grp["det_event"])
+                    with torch.cuda.stream(self._copy_stream):
                         t0 = time.perf_counter()
                         res = self.detector.detect_finish(grp["det"], h["arrays"][lo:hi], profile=profile)
                         order_h, keep_h = grp["ro"][0].cpu().numpy(), grp["ro"][1].cpu().numpy()

@@ -20,6 +20,7 @@
 // 56-67 with Cin >= 128.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msocr.h"
 
@@ -76,16 +77,19 @@ struct Gemm4Params {
   int Cin, Cout, ktiles, tilesM, tilesN;
 };
 
-constexpr int RS_BM = 64, RS_BN = 128, RS_BKB = 64;  // 64 tiles x 128 couts per workgroup, K-tiles of 16 f32 (64-byte rows)
-constexpr int RS_A_BYTES = 4 * RS_BM * RS_BKB, RS_B_BYTES = 4 * RS_BN * RS_BKB;
-constexpr int RS_EPI_BYTES = RS_BM * RS_BN * 4;
-constexpr int RS_LDS = (RS_A_BYTES + RS_B_BYTES) > RS_EPI_BYTES ? (RS_A_BYTES + RS_B_BYTES) : RS_EPI_BYTES;
+constexpr int RS_BN = 128, RS_BKB = 64;  // BM tiles x 128 couts per workgroup, K-tiles of 16 f32 (64-byte rows)
+constexpr int RS_B_BYTES = 4 * RS_BN * RS_BKB;
+template <int BM> constexpr int rs_lds() { return (4 * BM * RS_BKB + RS_B_BYTES) > BM * RS_BN * 4 ? (4 * BM * RS_BKB + RS_B_BYTES) : BM * RS_BN * 4; }
 
 __device__ __forceinline__ int rs_swz(int row) { return (row >> 2) & 3; }  // 64-byte rows: 4 rows per 256-byte bank line
 
-__global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
+// RS_BM = 64: 128 accumulator registers per lane, 2 workgroups per CU; RS_BM = 32: 64 registers, 3 per CU, twice the weight re-reads
+template <int RS_BM>
+__global__ __launch_bounds__(256, RS_BM == 64 ? 2 : 3) void wino_gemm4_kernel(Gemm4Params p) {
+  constexpr int RS_A_BYTES = 4 * RS_BM * RS_BKB;
+  constexpr int TMR = RS_BM / 16;           // 16-row MFMA tiles per wave along the tile dimension
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sa = smem;                 // [4 points][64 rows][64 B]
+  unsigned char* sa = smem;                 // [4 points][BM rows][64 B]
   unsigned char* sb = smem + RS_A_BYTES;    // [4 points][128 rows][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -103,10 +107,11 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
   const int tile_n = bid / p.tilesM, tile_m = bid - tile_n * p.tilesM;
 
   // ---- operand staging coordinates
-  const int a_row = tid >> 2, chunk = tid & 3;  // A: one (tile row, 16-byte chunk) per thread
+  const int a_row = tid >> 2, chunk = tid & 3;  // A: one (tile row, 16-byte chunk) per thread (the first 4 * BM threads)
+  const bool a_on = a_row < RS_BM;
   const float* a_ptr;
   {
-    long m = (long)tile_m * RS_BM + a_row;
+    long m = (long)tile_m * RS_BM + (a_on ? a_row : 0);
     if (m >= p.g.Mt) m = p.g.Mt - 1;  // rows past the end load valid data that the epilogue never stores
     const long rq = m / p.g.TW;
     const int tw = (int)(m - rq * p.g.TW);
@@ -122,19 +127,23 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
   f32x4 qa[4];
   u32x4 rb[8];
   auto load_tile = [&](int kt) {
+    if (a_on) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qa[j] = *reinterpret_cast<const f32x4*>(a_ptr + (long)j * p.Cin + kt * 16);
+      for (int j = 0; j < 4; ++j) qa[j] = *reinterpret_cast<const f32x4*>(a_ptr + (long)j * p.Cin + kt * 16);
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) rb[it] = *reinterpret_cast<const u32x4*>(b_ptr[it] + kt * 16);
   };
   auto store_tile = [&]() {
     // column pass of the input transform (the second half of B^T d B), same operations as wino_input_kernel
-    const f32x4 v0 = qa[0] - qa[2], v1 = qa[1] + qa[2], v2 = qa[2] - qa[1], v3 = qa[1] - qa[3];
-    unsigned char* dst = sa + a_row * RS_BKB + ((chunk ^ rs_swz(a_row)) << 4);
-    *reinterpret_cast<f32x4*>(dst) = v0;
-    *reinterpret_cast<f32x4*>(dst + RS_BM * RS_BKB) = v1;
-    *reinterpret_cast<f32x4*>(dst + 2 * RS_BM * RS_BKB) = v2;
-    *reinterpret_cast<f32x4*>(dst + 3 * RS_BM * RS_BKB) = v3;
+    if (a_on) {
+      const f32x4 v0 = qa[0] - qa[2], v1 = qa[1] + qa[2], v2 = qa[2] - qa[1], v3 = qa[1] - qa[3];
+      unsigned char* dst = sa + a_row * RS_BKB + ((chunk ^ rs_swz(a_row)) << 4);
+      *reinterpret_cast<f32x4*>(dst) = v0;
+      *reinterpret_cast<f32x4*>(dst + RS_BM * RS_BKB) = v1;
+      *reinterpret_cast<f32x4*>(dst + 2 * RS_BM * RS_BKB) = v2;
+      *reinterpret_cast<f32x4*>(dst + 3 * RS_BM * RS_BKB) = v3;
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = a_row + 64 * it;
@@ -142,11 +151,11 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
     }
   };
 
-  f32x4 acc[4][4][2];
+  f32x4 acc[4][TMR][2];
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMR; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[pt][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -157,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
     if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
-      u32x4 fa[4], fb[2];
+      u32x4 fa[TMR], fb[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TMR; ++i) {
         const int row = i * 16 + r16;
         fa[i] = *reinterpret_cast<const u32x4*>(sa + pt * RS_BM * RS_BKB + row * RS_BKB + ((kq ^ rs_swz(row)) << 4));
       }
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMR; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[pt][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[pt][i][j], 0, 0, 0);
@@ -182,13 +191,13 @@ __global__ __launch_bounds__(256, 2) void wino_gemm4_kernel(Gemm4Params p) {
   }
 
   // ---- epilogue: column pass of the output transform (A^T M A's "M A"), then the two R planes through LDS -> 16-byte stores
-  float* sc = reinterpret_cast<float*>(smem);  // [64 rows][128 couts] f32
+  float* sc = reinterpret_cast<float*>(smem);  // [BM rows][128 couts] f32
   const int vcol = (tid & 31) * 4, vrow0 = tid >> 5;  // 32 threads per row of 128 couts, 8 rows per sweep
 #pragma unroll
   for (int jo = 0; jo < 2; ++jo) {
     if (jo) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMR; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -292,17 +301,22 @@ extern "C" int msocr_winograd_rs_gemm(const msocr_conv_desc* d, const float* u_w
   p.g = g;
   p.Cin = d->Cin; p.Cout = d->Cout;
   p.ktiles = d->Cin / 16;
-  p.tilesM = (int)((g.Mt + RS_BM - 1) / RS_BM);
+  const int bm = getenv("MSOCR_WINO_RS_BM") ? atoi(getenv("MSOCR_WINO_RS_BM")) : 64;  // 32: 3 workgroups per CU (diagnostic)
+  p.tilesM = (int)((g.Mt + bm - 1) / bm);
   p.tilesN = d->Cout / RS_BN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, rs_lds<64>()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm4_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, rs_lds<32>()) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr_set = true;
   }
   const long nblk = 4L * p.tilesM * p.tilesN;
   if (nblk > 0x7fffffffL) return MSOCR_E_ARG;
-  MSOCR_LAUNCH(wino_gemm4_kernel, dim3((unsigned)nblk), dim3(256), RS_LDS, (hipStream_t)stream, p);
+  if (bm == 32)
+    MSOCR_LAUNCH(wino_gemm4_kernel<32>, dim3((unsigned)nblk), dim3(256), rs_lds<32>(), (hipStream_t)stream, p);
+  else
+    MSOCR_LAUNCH(wino_gemm4_kernel<64>, dim3((unsigned)nblk), dim3(256), rs_lds<64>(), (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 

@@ -469,3 +469,42 @@ def test_whole_pipeline_hipgraph_replay_equals_eager(gpu):
     assert len(set(counts)) >= 2 and min(counts) > 20
     assert any(pool["inst"] for pool in graph.recognizer._graphs.values()), "the recogniser never replayed a graph"
     assert any(pool["inst"] for pool in graph.detector._graphs.values())
+
+
+def test_device_reading_order_fallback_flags_and_host_path(gpu, monkeypatch):
+    """Pages the reading-order kernel cannot take are flagged (ncrop = -1), never mis-ordered: more intersecting pairs than the pair
+    buffer holds, more text lines than fit LDS.  A flagged page sends its group through the host path, with identical results."""
+    from manuscript_ocr_amd import Pipeline, ops, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    # (a) 300 boxes that all intersect each other: 44 850 pairs > 8 * cap + 4096
+    rng = np.random.default_rng(2)
+    b = [[int(x), int(y), int(x) + 400, int(y) + 300] for x, y in zip(rng.integers(0, 60, 300), rng.integers(0, 60, 300))]
+    assert _ro_case(ops, b, (1000, 1000))[3] == -1
+    # (b) 4200 one-word lines (more than the 4096 line slots); 4000 lines are fine
+    many = [[10, 12 * i, 60, 12 * i + 8] for i in range(4200)]
+    assert _ro_case(ops, many, (60000, 200))[3] == -1
+    order, keep, desc, nc = _ro_case(ops, many[:4000], (60000, 200))
+    assert nc == 4000 and order.tolist() == list(range(4000))
+    # (c) the pipeline with every page flagged == the pipeline with the device path
+    H, W = 256, 384
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda"),
+                    TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda"))
+    pages, maps = [], []
+    for seed in (71, 72):
+        pg, rects = synth.synth_page(seed, H, W)
+        pages.append(pg)
+        maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+    mo = (torch.from_numpy(np.stack([m[0] for m in maps])).cuda(), torch.from_numpy(np.stack([m[1] for m in maps])).cuda())
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    a = pipe.predict_batch(pages, _maps_override=mo)
+    real = ops.reading_order_crops
+
+    def flagged(*args, **kw):
+        order, keep, desc, ncrop = real(*args, **kw)
+        return order, keep, desc, torch.full_like(ncrop, -1)
+
+    monkeypatch.setattr(ops, "reading_order_crops", flagged)
+    assert [key(p) for p in pipe.predict_batch(pages, _maps_override=mo)] == [key(p) for p in a]
+    assert sum(len(k) for k in map(key, a)) > 10

@@ -67,3 +67,18 @@ def test_jpeg_unsupported_streams_are_reported():
     cmyk = io.BytesIO()
     Image.fromarray(arr).convert("CMYK").save(cmyk, format="JPEG")
     assert ingest.decode_jpeg_host(cmyk.getvalue()) is None
+
+
+def test_jpeg_restart_intervals_every_subsampling_and_awkward_sizes():
+    """Restart markers with each chroma layout, widths / heights around the MCU sizes (8, 16) incl. 1-pixel images."""
+    rng = np.random.default_rng(9)
+    for (h, w) in ((1, 1), (7, 9), (8, 16), (15, 17), (16, 33), (31, 47), (64, 3), (2, 130)):
+        arr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        for sub in (0, 1, 2):
+            for kw in ({}, {"restart_marker_blocks": 1}, {"restart_marker_rows": 1}):
+                try:
+                    data = _encode(arr, quality=60, subsampling=sub, **kw)
+                except TypeError:
+                    continue
+                got = ingest.decode_jpeg_host(data)
+                assert got is not None and np.array_equal(got, _pil_decode(data)), (h, w, sub, kw)

@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_STAGE = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel")
+CONV_STAGE = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
 def one(pattern):
@@ -32,7 +32,7 @@ def pmc(d, counter):
     for r in csv.DictReader(open(one(os.path.join(d, "runc", "*_counter_collection.csv")))):
         if r["Counter_Name"] != counter:
             continue
-        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         a = agg[n]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
@@ -61,8 +61,8 @@ def main():
     res = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                    "--no-cpu-baseline --no-roofline --steps 1 --warmup 1",
-        "kernels": "convolution stage = conv_igemm_kernel (all instances: Winograd GEMMs + direct convolutions) + wino_input_kernel + "
-                   "wino_output_kernel",
+        "kernels": "convolution stage = conv_igemm_kernel (all instances: Winograd GEMMs + direct convolutions) + wino_gemm4_kernel + "
+                   "the Winograd transform kernels (wino_input / wino_output / wino_rows_in / wino_rows_out)",
         "gfx950_correction": "FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",
         "hbm_bytes_per_step": tot,
         "per_kernel": per,
@@ -72,7 +72,7 @@ def main():
         gui = pmc(mfma, "GRBM_GUI_ACTIVE")
         mm = {}
         for n in busy:
-            if n.startswith("conv_igemm_kernel") and gui[n][1] > 0:
+            if n.startswith(("conv_igemm_kernel", "wino_gemm4_kernel")) and gui[n][1] > 0:
                 mm[n] = {"dispatches": busy[n][0], "SQ_VALU_MFMA_BUSY_CYCLES": busy[n][1], "GRBM_GUI_ACTIVE_sum_8xcd": gui[n][1],
                          "kernel_ns": gui[n][2],
                          "mfma_pipe_busy_fraction": busy[n][1] / (gui[n][1] / 8.0 * 1024.0),   # 1024 SIMDs, GUI summed over 8 XCDs
