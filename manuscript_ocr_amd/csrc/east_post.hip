@@ -400,16 +400,25 @@ __device__ __forceinline__ unsigned long long sortable_f64(double x) {
 
 #define RS_TILE 2048
 #define RS_Q 8
-// x0 sort of every page's candidates, spread over the whole chip: grid (chunks, pages), each workgroup ranks
-// 256*RS_Q candidates of one page against all n (keys staged through LDS as 64-bit (key, index) words).
-__global__ __launch_bounds__(256) void lanms_rank_x0_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
-                                                             int max_cand, char* __restrict__ ws, long ws_stride, long order_off) {
-  const int pg = blockIdx.y, tid = threadIdx.x;
+// x0 sort of every page's candidates, spread over the whole chip: grid (i chunks, j chunks, pages).  A workgroup counts, for its
+// 256*RS_Q candidates, how many of ITS RS_TILE candidates j sort before them (keys staged through LDS as 64-bit (key, index)
+// words) and adds that partial rank into rank_acc (zeroed by lanms_zero_kernel); the page kernel then scatters order[rank] = i.
+// (Round 1 ran one workgroup per i chunk over ALL j: 5 workgroups per 10 k-candidate page, 0.59 ms; the 2-D split is ~n/2048
+// times more parallel.)
+__global__ __launch_bounds__(256) void lanms_zero_kernel(const int32_t* __restrict__ counts, char* __restrict__ ws, long ws_stride, long acc_off) {
+  const int pg = blockIdx.y;
   const int n = counts[pg] & 0x7fffffff;
-  const int i0 = blockIdx.x * 256 * RS_Q;
-  if (i0 >= n) return;
+  int32_t* acc = reinterpret_cast<int32_t*>(ws + (long)pg * ws_stride + acc_off);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc[i] = 0;
+}
+__global__ __launch_bounds__(256) void lanms_rank_x0_kernel(const float* __restrict__ cand, const int32_t* __restrict__ counts,
+                                                             int max_cand, char* __restrict__ ws, long ws_stride, long acc_off) {
+  const int pg = blockIdx.z, tid = threadIdx.x;
+  const int n = counts[pg] & 0x7fffffff;
+  const int i0 = blockIdx.x * 256 * RS_Q, j0 = blockIdx.y * RS_TILE;
+  if (i0 >= n || j0 >= n) return;
   const float* cb = cand + (long)pg * max_cand * 9;
-  int32_t* order = reinterpret_cast<int32_t*>(ws + (long)pg * ws_stride + order_off);
+  int32_t* acc = reinterpret_cast<int32_t*>(ws + (long)pg * ws_stride + acc_off);
   __shared__ unsigned long long tile[RS_TILE];
   unsigned long long ki[RS_Q];
   int rank[RS_Q];
@@ -419,21 +428,18 @@ __global__ __launch_bounds__(256) void lanms_rank_x0_kernel(const float* __restr
     ki[q] = i < n ? (((unsigned long long)sortable_f32(cb[(long)i * 9]) << 32) | (unsigned)i) : 0ull;
     rank[q] = 0;
   }
-  for (int j0 = 0; j0 < n; j0 += RS_TILE) {
-    const int jn = min(RS_TILE, n - j0);
-    __syncthreads();
-    for (int j = tid; j < jn; j += 256) tile[j] = ((unsigned long long)sortable_f32(cb[(long)(j0 + j) * 9]) << 32) | (unsigned)(j0 + j);
-    __syncthreads();
-    for (int j = 0; j < jn; ++j) {
-      const unsigned long long kj = tile[j];
+  const int jn = min(RS_TILE, n - j0);
+  for (int j = tid; j < jn; j += 256) tile[j] = ((unsigned long long)sortable_f32(cb[(long)(j0 + j) * 9]) << 32) | (unsigned)(j0 + j);
+  __syncthreads();
+  for (int j = 0; j < jn; ++j) {
+    const unsigned long long kj = tile[j];
 #pragma unroll
-      for (int q = 0; q < RS_Q; ++q) rank[q] += kj < ki[q] ? 1 : 0;
-    }
+    for (int q = 0; q < RS_Q; ++q) rank[q] += kj < ki[q] ? 1 : 0;
   }
 #pragma unroll
   for (int q = 0; q < RS_Q; ++q) {
     const int i = i0 + q * 256 + tid;
-    if (i < n) order[rank[q]] = i;
+    if (i < n && rank[q]) atomicAdd(&acc[i], rank[q]);
   }
 }
 
@@ -539,12 +545,14 @@ __global__ __launch_bounds__(TT) void east_lanms_kernel(const float* __restrict_
     if (tid == 0) { nbox_out[pg] = 0; nm_hdr[0] = -1; }
     return;
   }
-  // ---- `order` already holds the stable argsort by x0 (lanms.py:166-168), computed by lanms_rank_x0_kernel
+  // ---- `supp` holds every candidate's rank in the stable argsort by x0 (lanms.py:166-168), accumulated by lanms_rank_x0_kernel
   __shared__ unsigned long long rs_tile[RS_TILE];
   for (int i = tid; i < n; i += nthr) {
+    order[supp[i]] = i;
     flag[i] = 0;
     sbreak[i] = 0;
   }
+  __threadfence();
   __syncthreads();
   DBG_STAMP(1);
   // ---- phase 1: speculative segmented scan -------------------------------------------------------------
@@ -838,10 +846,14 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
     }
   }
   {
-    const long order_off = ((long)max_cand * (2 * (64 + 8)) + (long)3 * LANMS_T * CARRY_W * 8);
-    const int chunks = (max_cand + 256 * RS_Q - 1) / (256 * RS_Q);
-    MSOCR_LAUNCH(lanms_rank_x0_kernel, dim3(chunks, N), dim3(256), 0, (hipStream_t)stream, cand, counts, max_cand, (char*)workspace, stride,
-                 order_off);
+    // rank accumulator = the `supp` array of the page workspace (order | supp | flag | sbreak, 4 bytes each per candidate)
+    const long acc_off = ((long)max_cand * (2 * (64 + 8)) + (long)3 * LANMS_T * CARRY_W * 8) + (long)max_cand * 4;
+    const int ichunks = (max_cand + 256 * RS_Q - 1) / (256 * RS_Q), jchunks = (max_cand + RS_TILE - 1) / RS_TILE;
+    if (jchunks > 65535 || N > 65535) return MSOCR_E_ARG;
+    MSOCR_LAUNCH(lanms_zero_kernel, dim3(min(ichunks * RS_Q, 64), N), dim3(256), 0, (hipStream_t)stream, counts, (char*)workspace, stride, acc_off);
+    if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+    MSOCR_LAUNCH(lanms_rank_x0_kernel, dim3(ichunks, jchunks, N), dim3(256), 0, (hipStream_t)stream, cand, counts, max_cand, (char*)workspace,
+                 stride, acc_off);
     if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
   }
   long long* dbg = nullptr;
@@ -872,7 +884,7 @@ extern "C" int msocr_east_lanms(const float* cand, const int32_t* counts, int N,
                  nbox_out, (char*)workspace, stride, dbg, bits_off, bitcap);
   int rc = LAUNCH_OK();
   if (rc == MSOCR_OK && bitcap > 0) {
-    MSOCR_LAUNCH(lanms_iou_bits_kernel, dim3(64, N), dim3(256), 0, (hipStream_t)stream, (char*)workspace, stride, max_cand, iou_thr, bits_off,
+    MSOCR_LAUNCH(lanms_iou_bits_kernel, dim3(256, N), dim3(256), 0, (hipStream_t)stream, (char*)workspace, stride, max_cand, iou_thr, bits_off,
                  bitcap);
     rc = LAUNCH_OK();
     if (rc == MSOCR_OK) {
