@@ -21,8 +21,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime is loaded (manuscript_ocr_amd/__init__.py explains)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -125,7 +127,8 @@ def main():
 
     # detector-only workload (BASELINE configs[1]): groups of 2 pages on their own streams, two stream sets, the groups of step
     # i+1 enqueued before step i's boxes are read back and filtered on the host
-    east_bounds = [(lo, min(lo + 2, NP)) for lo in range(0, NP, 2)]
+    east_group = int(os.environ.get("MSOCR_EAST_GROUP", "4"))  # pages per detector launch sequence: 104 / 108 / 140 / 135 pages/s at 1 / 2 / 4 / 8
+    east_bounds = [(lo, min(lo + east_group, NP)) for lo in range(0, NP, east_group)]
     east_streams = [[torch.cuda.Stream() for _ in east_bounds] for _ in range(2)] if pipe is None else None
 
     def east_submit(i):

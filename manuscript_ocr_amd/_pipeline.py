@@ -217,7 +217,11 @@ class Pipeline:
             else:
                 pages_dev = torch.stack([t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(det.device)
                                          for t, a in zip(decoded, arrays)])
-        nsub = sub_batches or min(8, max(1, N // 2))  # >= 2 pages per group; 8 groups measured best at 16 pages
+        # groups per batch.  Round 1 needed 8 groups of 2 pages to hide its host stages behind other groups' device work; with the
+        # reading order on the device and Page assembly off the enqueue path, larger launch sequences win (bigger GEMM M, fewer
+        # launches): 16 pages measured 44.0 / 45.4 / 45.7 pages/s at 8 / 4 / 2 groups with 4 hardware queues and 36.3 / 46.8 / 48.1
+        # with 8; one group ties two at lower memory, two keeps a second detector sequence in flight
+        nsub = sub_batches or (2 if N >= 8 else 1)
         nsub = max(1, min(nsub, N))
         bounds = [(N * k // nsub, N * (k + 1) // nsub) for k in range(nsub)]
         main = torch.cuda.current_stream()
