@@ -408,7 +408,9 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
       if (wide && variant == 1 && mt16 == 2 && !(lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0))
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, false, 16>(p, s);
       if (wide && variant == 1 && lean_on && mt16 && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0) {
-        const int gv = getenv("MSOCR_GEMM_VARIANT") ? atoi(getenv("MSOCR_GEMM_VARIANT")) : 0;  // diagnostics (tools/gemm_probe.py)
+        // default 2: K-tiles of 16 (64-byte rows), 128 VGPRs, FOUR workgroups per CU: +1-2 % on the short-K launches in isolation
+        // (tools/gemm_probe.py) and +2.3 % on the pipeline (49.3 against 48.2 pages/s, three A/B pairs); 0 = K-tiles of 32 at 3 per CU
+        const int gv = getenv("MSOCR_GEMM_VARIANT") ? atoi(getenv("MSOCR_GEMM_VARIANT")) : 2;
         if (gv == 1 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1, true, 16, 2>(p, s);  // BK = 64, 2 per CU
         if (gv == 2) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);                              // BK = 16, 4 per CU
         if (gv == 3) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 3, 8>(p, s);                          // staggered start

@@ -93,8 +93,10 @@ def _wino_workspace(nbytes, device):
 
 # Row-split Winograd form (csrc/winograd_rs.hip: half the transform traffic, a 4-point GEMM at 2 workgroups per CU).  Measured
 # per layer (tools/conv_bench.py): Cin = 256 layers 6-9 % faster than the plain form, Cin = 512 layers 2 % slower (the GEMM's lower
-# occupancy costs more than the transforms save), so: 1 = layers with Cin <= 256 (default), 2 = every supported layer, 0 = off.
-WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "1"))
+# occupancy costs more than the transforms save).  In the pipeline (three A/B pairs, 16 pages per step): off 48.5 / Cin <= 256 48.2 /
+# every layer 45.9 pages/s, with 655 / 587 / ~445 GB of HBM traffic per step — so it is OFF by default and kept as the low-traffic
+# option: 0 = off (default), 1 = layers with Cin <= 256, 2 = every supported layer.
+WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "0"))
 
 
 def attach_winograd(w):
