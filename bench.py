@@ -325,15 +325,15 @@ def main():
         gemm_ms = union_ms([(s_, e_) for s_, e_, _, _ in gemm])
         res["roofline"] = {
             "kernel": "conv_igemm_kernel (implicit-GEMM convolution on the f32 matrix cores: direct convolutions, 1x1 layers, the "
-                      "LSTM/linear GEMMs and the 16-GEMM launch of every Winograd F(2x2,3x3) layer), over the convolution stage = "
+                      "LSTM/linear GEMMs and the 24-GEMM launch of every Winograd F(4,3)xF(2,3) layer), over the convolution stage = "
                       "those launches + the Winograd transform kernels around them",
             "bound": "mfma",
             "achieved": executed / (stage_ms * 1e-3) / 1e12,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": executed / (stage_ms * 1e-3) / 1e12 / peak,
-            "definition": "achieved = FLOP the MFMAs EXECUTE (Winograd layers: 2*16*tiles*Cin*Cout, 2.25x fewer than the direct "
-                          "form) / time in which at least one conv-stage kernel is executing (HIP events on the launch streams, "
+            "definition": "achieved = FLOP the MFMAs EXECUTE (Winograd layers: 2*24*tiles*Cin*Cout per 4x2-output tile, 3x fewer "
+                          "than the direct form) / time in which at least one conv-stage kernel is executing (HIP events on the launch streams, "
                           "sub-batch streams overlapping as in the timed region); <= 1 by construction",
             "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": executed / (gemm_ms * 1e-3) / 1e12 / peak,
                                  "busy_ms_per_step": gemm_ms / a.steps},

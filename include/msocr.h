@@ -74,6 +74,20 @@ int msocr_winograd_gemm(const msocr_conv_desc* d, const float* u_weight, void* w
 int msocr_winograd_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
                                     void* out, void* stream);
 
+/* The same convolution in the TALL Winograd form F(4,3) x F(2,3) (6x4 input tile -> 4x2 output tile, 24 transform points:
+ * 3 multiplies per output where F(2x2,3x3) spends 4 and the direct form 9; V / Mw are 3x the layer's arrays instead of 4x).
+ * Only the H axis takes the 6-point transform, whose constants grow the layer's f32 rounding error ~2.5x rms over F(2x2)
+ * (DESIGN.md section 4).  u_weight = [24][Cout][Cin] f32 on the DEVICE from msocr_winograd42_weights_host (HOST function, f64,
+ * rounded once).  Same shape rules, workspace convention and stage entry points as msocr_conv3x3_winograd. */
+int64_t msocr_conv3x3_winograd42_workspace_bytes(const msocr_conv_desc* d);
+int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                             const void* residual, void* out, void* workspace, void* stream);
+int msocr_winograd42_weights_host(const float* w_khwc_host, int Cout, int Cin, float* u_out_host);
+int msocr_winograd42_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream);
+int msocr_winograd42_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream);
+int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
+                                      void* out, void* stream);
+
 /* The same convolution in the ROW-SPLIT Winograd form (csrc/winograd_rs.hip): the transforms are split by axis around a GEMM whose
  * workgroups own the 4 points of one transform row, so the arrays streamed through HBM are Q = (B^T d) (2x the input) and
  * R = (M A) (2x the output) instead of V and Mw (4x each): 10 units of traffic per layer instead of 18.  Same u_weight as

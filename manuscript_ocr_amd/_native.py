@@ -48,6 +48,12 @@ _SIGS = {
     "msocr_winograd_input_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_winograd_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_winograd_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd42_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "msocr_conv3x3_winograd42": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_winograd42_weights_host": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "msocr_winograd42_input_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd42_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd42_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd_rs_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd_rs": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd_rs_rows_in": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),

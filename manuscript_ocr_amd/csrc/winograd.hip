@@ -199,6 +199,200 @@ extern "C" int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, 
   return msocr_winograd_output_transform(d, workspace, bias, residual, out, stream);
 }
 
+// =====================================================================================================================
+// The TALL form: F(4,3) along H x F(2,3) along W.  A 6x4 input tile gives a 4x2 output tile through 24 transform-domain
+// products: 3 multiplies per output instead of 4 (direct: 9), V / Mw expanded 3x instead of 4x.  Only the H axis takes the
+// 6-point transform: its constants (4, 5, 2, 8; 1/6, 1/24 in the weights) grow the f32 rounding error of the layer by ~2.5x rms
+// over F(2x2) (measured against f64: DESIGN.md section 4), where the 6x6 form would grow it 6x.  ops.conv2d() picks this form
+// when 24 * ceil(H/4) < 16 * ceil(H/2) (H = 4, 7, 8, >= 11 ...: every map of the pipeline), the 2x2 form otherwise.
+//   V[(xi*4+nu)][tile][c], xi = 0..5 (H axis), nu = 0..3 (W axis); Mw likewise; U from msocr_winograd42_weights_host.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void wino42_input_kernel(const float* __restrict__ in, long sN, long sH, long sW, int C,
+                                                            WinoGeom g, float* __restrict__ V) {
+  const int cch = C >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const int h0 = 4 * th - 1, w0 = 2 * tw - 1;
+  const float* base = in + (long)n * sN + c;
+  // W axis first (B4^T per row as the row is loaded), then the 6-point H transform per column
+  f32x4 q[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int hi = h0 + i;
+    const bool okh = (unsigned)hi < (unsigned)g.H;
+    f32x4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wi = w0 + j;
+      const bool ok = okh && (unsigned)wi < (unsigned)g.W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + (long)hi * sH + (long)wi * sW : base);
+      d[j] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    q[i][0] = d[0] - d[2];
+    q[i][1] = d[1] + d[2];
+    q[i][2] = d[2] - d[1];
+    q[i][3] = d[1] - d[3];
+  }
+  const long plane = g.Mt * (long)C;
+  float* o = V + t * (long)C + c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 a0 = q[0][j], a1 = q[1][j], a2 = q[2][j], a3 = q[3][j], a4 = q[4][j], a5 = q[5][j];
+    const f32x4 e42 = a4 - a2, e31 = a3 - a1;
+    *reinterpret_cast<f32x4*>(o + (0 * 4 + j) * plane) = (4.f * a0 - 5.f * a2) + a4;
+    *reinterpret_cast<f32x4*>(o + (1 * 4 + j) * plane) = (a3 + a4) - 4.f * (a1 + a2);
+    *reinterpret_cast<f32x4*>(o + (2 * 4 + j) * plane) = (a4 - a3) + 4.f * (a1 - a2);
+    *reinterpret_cast<f32x4*>(o + (3 * 4 + j) * plane) = e42 + 2.f * e31;
+    *reinterpret_cast<f32x4*>(o + (4 * 4 + j) * plane) = e42 - 2.f * e31;
+    *reinterpret_cast<f32x4*>(o + (5 * 4 + j) * plane) = (4.f * a1 - 5.f * a3) + a5;
+  }
+}
+
+__global__ __launch_bounds__(256) void wino42_output_kernel(const float* __restrict__ Mw, int Cout, WinoGeom g,
+                                                             const float* __restrict__ bias, const float* __restrict__ res,
+                                                             long res_ld, int relu, float* __restrict__ out, long out_ld) {
+  const int cch = Cout >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const long plane = g.Mt * (long)Cout;
+  const float* mp = Mw + t * (long)Cout + c;
+  // H axis first (A6^T per column as the column is loaded), then A4^T along W
+  f32x4 s[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 m[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + (i * 4 + j) * plane);
+    const f32x4 p12 = m[1] + m[2], d12 = m[1] - m[2], p34 = m[3] + m[4], d34 = m[3] - m[4];
+    s[0][j] = (m[0] + p12) + p34;
+    s[1][j] = d12 + 2.f * d34;
+    s[2][j] = p12 + 4.f * p34;
+    s[3][j] = (d12 + 8.f * d34) + m[5];
+  }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ho = 4 * th + i;
+    if (ho >= g.H) continue;
+    f32x4 y[2];
+    y[0] = (s[i][0] + s[i][1]) + s[i][2];
+    y[1] = (s[i][1] - s[i][2]) - s[i][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int wo = 2 * tw + j;
+      if (wo >= g.W) continue;
+      const long pix = ((long)n * g.H + ho) * g.W + wo;
+      f32x4 v = y[j] + b;
+      if (res) v += *reinterpret_cast<const f32x4*>(res + pix * res_ld + c);
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+  }
+}
+
+static bool wino42_geom(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino_geom(d, g)) return false;
+  g->TH = (d->H + 3) / 4;
+  g->Mt = (long)d->N * g->TH * g->TW;
+  return 24 * g->Mt * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) <= 0x3fffffffffffL;
+}
+
+extern "C" int64_t msocr_conv3x3_winograd42_workspace_bytes(const msocr_conv_desc* d) {
+  WinoGeom g;
+  if (!wino42_geom(d, &g)) return -1;
+  return 24 * g.Mt * ((int64_t)d->Cin + d->Cout) * (int64_t)sizeof(float);
+}
+
+static int wino42_check(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino42_geom(d, g)) return MSOCR_E_ARG;
+  if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  return MSOCR_OK;
+}
+
+extern "C" int msocr_winograd42_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino42_check(d, &g) != MSOCR_OK || !in || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const long nb_in = (g.Mt * (d->Cin / 4) + 255) / 256;
+  if (nb_in > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino42_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, (hipStream_t)stream, (const float*)in, (long)d->in_sN,
+               (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_winograd42_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino42_check(d, &g) != MSOCR_OK || !u_weight || !workspace) return MSOCR_E_ARG;
+  float* V = (float*)workspace;
+  return msocr_internal_gemm_f32_batched(V, u_weight, V + 24 * g.Mt * (long)d->Cin, g.Mt, d->Cout, d->Cin, 24, (hipStream_t)stream);
+}
+
+extern "C" int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias,
+                                                 const void* residual, void* out, void* stream) {
+  WinoGeom g;
+  if (wino42_check(d, &g) != MSOCR_OK || !out || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)out | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  if (bias && ((uintptr_t)bias & 15)) return MSOCR_E_ARG;
+  const long nb_out = (g.Mt * (d->Cout / 4) + 255) / 256;
+  if (nb_out > 0x7fffffffL) return MSOCR_E_ARG;
+  const float* Mw = (const float*)workspace + 24 * g.Mt * (long)d->Cin;
+  MSOCR_LAUNCH(wino42_output_kernel, dim3((unsigned)nb_out), dim3(256), 0, (hipStream_t)stream, Mw, d->Cout, g, bias,
+               has_res ? (const float*)residual : nullptr, (long)d->res_ld, (d->flags & MSOCR_CONV_RELU) ? 1 : 0, (float*)out,
+               (long)d->out_ld);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                                        const void* residual, void* out, void* workspace, void* stream) {
+  if (!u_weight) return MSOCR_E_ARG;
+  int rc = msocr_winograd42_input_transform(d, in, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  rc = msocr_winograd42_gemm(d, u_weight, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  return msocr_winograd42_output_transform(d, workspace, bias, residual, out, stream);
+}
+
+// U[xi*4+nu][co][c] = sum_{kh,kw} G6[xi][kh] G4[nu][kw] w[co][kh][kw][c] (xi = 0..5 on the kernel's H axis), f64, rounded once.
+// HOST function like msocr_winograd_weights_host.
+extern "C" int msocr_winograd42_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {
+  if (!w_khwc || !u_out || Cout <= 0 || Cin <= 0) return MSOCR_E_ARG;
+  static const double G6[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  static const double G4[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const long plane = (long)Cout * Cin;
+  for (int co = 0; co < Cout; ++co) {
+    const float* w = w_khwc + (long)co * 9 * Cin;
+    for (int c = 0; c < Cin; ++c) {
+      double gw[6][3];  // G6 g
+      for (int xi = 0; xi < 6; ++xi)
+        for (int kw = 0; kw < 3; ++kw)
+          gw[xi][kw] = G6[xi][0] * w[(0 * 3 + kw) * Cin + c] + G6[xi][1] * w[(1 * 3 + kw) * Cin + c] + G6[xi][2] * w[(2 * 3 + kw) * Cin + c];
+      for (int xi = 0; xi < 6; ++xi)
+        for (int nu = 0; nu < 4; ++nu)
+          u_out[(xi * 4 + nu) * plane + (long)co * Cin + c] =
+              (float)(gw[xi][0] * G4[nu][0] + gw[xi][1] * G4[nu][1] + gw[xi][2] * G4[nu][2]);
+    }
+  }
+  return MSOCR_OK;
+}
+
 // U[xi*4+nu][co][c] = sum_{kh,kw} G[xi][kh] G[nu][kw] w[co][kh][kw][c], evaluated in f64 and rounded once to f32.
 // HOST function (runs at weight-load time): w_khwc and u_out are host pointers.
 extern "C" int msocr_winograd_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {

@@ -99,9 +99,20 @@ def _wino_workspace(nbytes, device):
 WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "0"))
 
 
+# Tall Winograd form F(4,3) x F(2,3) (csrc/winograd.hip, wino42_*): 24 transform points per 4x2 outputs = 3 multiplies per output
+# instead of 4, V / Mw 3x instead of 4x.  Taken when it is cheaper for the map height: 24 * ceil(H/4) < 16 * ceil(H/2)
+# (H = 4, 7, 8, 11, 12, >= 15 ...).  MSOCR_WINO_TALL=0 keeps every layer on F(2x2,3x3).
+WINOGRAD_TALL = int(os.environ.get("MSOCR_WINO_TALL", "1"))
+
+
+def _tall_pays(H):
+    return 24 * (-(-H // 4)) < 16 * (-(-H // 2))
+
+
 def attach_winograd(w):
-    """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twin U = G g G^T ([16,Cout,Cin] f32, computed
-    on the host in f64 by msocr_winograd_weights_host).  conv2d() then takes the Winograd path for 3x3/1/1 calls."""
+    """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twins U = G g G^T ([16,Cout,Cin] f32 for F(2x2,3x3),
+    [24,Cout,Cin] for the tall form F(4,3) x F(2,3); computed on the host in f64 by msocr_winograd[42]_weights_host).  conv2d() then
+    takes the Winograd path for 3x3/1/1 calls."""
     Cout, KH, KW, Cin = w.shape
     if not (WINOGRAD_MIN_CIN and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin >= WINOGRAD_MIN_CIN and Cin % 16 == 0
             and Cout % 32 == 0):
@@ -110,6 +121,9 @@ def attach_winograd(w):
     u = torch.empty((16, Cout, Cin), dtype=torch.float32)
     nat.check(nat.lib().msocr_winograd_weights_host(wh.data_ptr(), Cout, Cin, u.data_ptr()), "winograd_weights_host")
     w._msocr_wino = u.to(w.device)
+    u42 = torch.empty((24, Cout, Cin), dtype=torch.float32)
+    nat.check(nat.lib().msocr_winograd42_weights_host(wh.data_ptr(), Cout, Cin, u42.data_ptr()), "winograd42_weights_host")
+    w._msocr_wino42 = u42.to(w.device)
     return w
 
 
@@ -150,19 +164,28 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     alg = 2.0 * N * Ho * Wo * Cout * (alg_k if alg_k else KH * KW * Cin)  # ALGORITHMIC direct-convolution FLOP (2 * MACs)
     if use_wino:
         L = nat.lib()
-        rs = Cout % 128 == 0 and (WINOGRAD_ROW_SPLIT >= 2 or (WINOGRAD_ROW_SPLIT == 1 and Cin <= 256))
-        nbytes = (L.msocr_conv3x3_winograd_rs_workspace_bytes if rs else L.msocr_conv3x3_winograd_workspace_bytes)(ctypes.byref(d))
+        tall = bool(WINOGRAD_TALL) and _tall_pays(H) and getattr(w, "_msocr_wino42", None) is not None
+        rs = (not tall) and Cout % 128 == 0 and (WINOGRAD_ROW_SPLIT >= 2 or (WINOGRAD_ROW_SPLIT == 1 and Cin <= 256))
+        if tall:
+            u = w._msocr_wino42
+            name, f_ws, whole = "winograd42", L.msocr_conv3x3_winograd42_workspace_bytes, L.msocr_conv3x3_winograd42
+            st_in, st_gemm, st_out = L.msocr_winograd42_input_transform, L.msocr_winograd42_gemm, L.msocr_winograd42_output_transform
+            TH, TW, npts = (Ho + 3) // 4, (Wo + 1) // 2, 24
+        elif rs:
+            name, f_ws, whole = "winograd_rs", L.msocr_conv3x3_winograd_rs_workspace_bytes, L.msocr_conv3x3_winograd_rs
+            st_in, st_gemm, st_out = L.msocr_winograd_rs_rows_in, L.msocr_winograd_rs_gemm, L.msocr_winograd_rs_rows_out
+            TH, TW, npts = (Ho + 1) // 2, (Wo + 1) // 2, 16
+        else:
+            name, f_ws, whole = "winograd", L.msocr_conv3x3_winograd_workspace_bytes, L.msocr_conv3x3_winograd
+            st_in, st_gemm, st_out = L.msocr_winograd_input_transform, L.msocr_winograd_gemm, L.msocr_winograd_output_transform
+            TH, TW, npts = (Ho + 1) // 2, (Wo + 1) // 2, 16
+        nbytes = f_ws(ctypes.byref(d))
         if nbytes < 0:
-            raise nat.NativeError(f"winograd: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")
+            raise nat.NativeError(f"{name}: unsupported shape {tuple(x.shape)} * {tuple(w.shape)}")
         parts = min(N, -(-nbytes // WINO_WS_LIMIT))  # images per call such that the workspace stays under the limit
         per = -(-N // parts)
         ws = _wino_workspace(nbytes if parts == 1 else (nbytes // N) * per, x.device)
-        what = f"msocr_conv3x3_winograd{'_rs' if rs else ''} {tuple(x.shape)} * {tuple(w.shape)}"
-        whole = L.msocr_conv3x3_winograd_rs if rs else L.msocr_conv3x3_winograd
-        st_in = L.msocr_winograd_rs_rows_in if rs else L.msocr_winograd_input_transform
-        st_gemm = L.msocr_winograd_rs_gemm if rs else L.msocr_winograd_gemm
-        st_out = L.msocr_winograd_rs_rows_out if rs else L.msocr_winograd_output_transform
-        TH, TW = (Ho + 1) // 2, (Wo + 1) // 2
+        what = f"msocr_conv3x3_{name} {tuple(x.shape)} * {tuple(w.shape)}"
         for n0 in range(0, N, per):
             n1 = min(N, n0 + per)
             d.N = n1 - n0
@@ -171,14 +194,14 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
                 nat.check(whole(ctypes.byref(d), xp, u.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
             else:  # the same three kernels through the per-stage entry points, one event pair each
                 nn, mt = n1 - n0, (n1 - n0) * TH * TW
-                v_el = 4 * nn * TH * (2 * TW + 2) * Cin if rs else 16 * mt * Cin  # transformed input array (Q or V), elements
-                m_el = (8 if rs else 16) * mt * Cout                              # transformed output array (R or Mw)
+                v_el = 4 * nn * TH * (2 * TW + 2) * Cin if rs else npts * mt * Cin  # transformed input array (Q or V), elements
+                m_el = (8 if rs else npts) * mt * Cout                              # transformed output array (R or Mw)
                 e = _prof_begin()
                 nat.check(st_in(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
                 _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + v_el), (mt, Cin))
                 e = _prof_begin()
                 nat.check(st_gemm(ctypes.byref(d), u.data_ptr(), ws.data_ptr(), _stream()), what)
-                _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 16 * mt * Cin * Cout), (nn * Ho * Wo, Cout, KH * KW * Cin, "winograd"))
+                _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * npts * mt * Cin * Cout), (nn * Ho * Wo, Cout, KH * KW * Cin, name))
                 e = _prof_begin()
                 nat.check(st_out(ctypes.byref(d), ws.data_ptr(), bp, rp_, op, _stream()), what)
                 _prof_end(e, "wino_out", 4.0 * (m_el + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))

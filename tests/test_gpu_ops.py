@@ -83,12 +83,17 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
-@pytest.mark.parametrize("row_split", [2, 0])
-def test_conv3x3_winograd_vs_direct_and_f64(ops, case, row_split, monkeypatch):
-    """Winograd F(2x2,3x3) path (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as
-    the direct kernel, and its error stays within 4x of the direct kernel's own error against f64 (rounding order only).
-    row_split = 2: the axis-split form on every layer it supports (csrc/winograd_rs.hip, Cout % 128 == 0) ; 0: the plain V / Mw form (csrc/winograd.hip)."""
-    monkeypatch.setattr(ops, "WINOGRAD_ROW_SPLIT", row_split)
+@pytest.mark.parametrize("form", ["tall", "rs", "plain"])
+def test_conv3x3_winograd_vs_direct_and_f64(ops, case, form, monkeypatch):
+    """Winograd paths (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as the direct kernel, and
+    the error stays within a small multiple of the direct kernel's own error against f64 (rounding order only).
+    tall: F(4,3) x F(2,3) (csrc/winograd.hip wino42_*; forced on every height here, so H = 1, 7, 17 exercise its partial tiles;
+    its 6-point H transform is allowed 8x the direct error, measured ~2-4x); rs: the axis-split F(2x2) form on every layer it supports
+    (csrc/winograd_rs.hip, Cout % 128 == 0); plain: the V / Mw F(2x2) form (csrc/winograd.hip)."""
+    monkeypatch.setattr(ops, "WINOGRAD_TALL", 1 if form == "tall" else 0)
+    monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
+    monkeypatch.setattr(ops, "WINOGRAD_ROW_SPLIT", 2 if form == "rs" else 0)
+    err_mult = 8 if form == "tall" else 4
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]))
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -111,7 +116,7 @@ def test_conv3x3_winograd_vs_direct_and_f64(ops, case, row_split, monkeypatch):
     scale = max(ref.abs().max().item(), 1.0)
     e_d = (out_d.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     e_w = (big[..., 32:].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
-    assert e_w <= 2e-5 * scale and e_w <= 4 * e_d + 1e-6 * scale, (e_w, e_d, scale)
+    assert e_w <= 2e-5 * scale and e_w <= err_mult * e_d + 1e-6 * scale, (e_w, e_d, scale)
     assert torch.all(big[..., :32] == 7.0)
 
 
@@ -123,6 +128,13 @@ def test_winograd_weight_transform_matches_definition(ops):
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
     exp = torch.einsum("xk,ockl,nl->xnoc", G, w.double(), G).reshape(16, 64, 128).float()
     assert torch.equal(wk._msocr_wino.cpu(), exp)
+    G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                       [0, 0, 1]], dtype=torch.float64)
+    exp42 = torch.einsum("xk,ockl,nl->xnoc", G6, w.double(), G).reshape(24, 64, 128)
+    got42 = wk._msocr_wino42.cpu()
+    assert got42.shape == (24, 64, 128)
+    # f64 evaluation in a different summation order than einsum's: equal after the single rounding to f32 up to 1 ulp
+    assert (got42.double() - exp42).abs().max().item() <= 1.2e-7 * exp42.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -9,10 +9,13 @@ SHAPES = [  # N, H, W, Cin, Cout, k, stride, pad
     (960, 8, 25, 256, 256, 3, 1, 1),
     (2048, 4, 13, 512, 512, 3, 1, 1),     # TRBA layer3/4 3x3 (45 launches/step)
     (2048, 8, 25, 256, 256, 3, 1, 1),     # TRBA layer2
+    (2048, 16, 50, 128, 128, 3, 1, 1),    # TRBA layer1
     (2048, 16, 50, 64, 128, 3, 1, 1),     # TRBA conv0b
     (4, 384, 512, 64, 256, 1, 1, 0),      # EAST layer1 1x1 64->256 (K=64)
     (4, 384, 512, 64, 64, 3, 1, 1),       # EAST layer1 3x3
     (4, 96, 128, 256, 256, 3, 1, 1),      # EAST layer3 3x3
+    (4, 48, 64, 512, 512, 3, 1, 1),       # EAST layer4 3x3
+    (4, 192, 256, 128, 128, 3, 1, 1),     # EAST layer2 3x3
     (4, 96, 128, 256, 1024, 1, 1, 0),     # EAST layer3 1x1
 ]
 
