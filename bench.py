@@ -357,7 +357,7 @@ def main():
                                        "avg_launch_ms": float(dur.mean()), "gemm_ms_per_step": float(dur.sum() / a.steps),
                                        "conv_stage_ms_per_step": float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])) / a.steps)}
         HBM_PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
-        names = {"wino_in": "wino_input_kernel", "wino_out": "wino_output_kernel", "se_residual": "se_residual_kernel",
+        names = {"wino_in": "wino42_input_kernel", "wino_out": "wino42_output_kernel", "se_residual": "se_residual_kernel",
                  "maxpool": "maxpool_kernel", "bilstm": "bilstm_kernel", "attn_beam": "attn_beam_mfma_kernel"}
         mean_run = (rec.last_run_length_sum / rec.last_rows) if (rec is not None and getattr(rec, "last_rows", 0)) else None
         sec = []

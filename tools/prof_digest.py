@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_STAGE = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+CONV_STAGE = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
 def one(pattern):
@@ -62,7 +62,7 @@ def main():
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                    "--no-cpu-baseline --no-roofline --steps 1 --warmup 1",
         "kernels": "convolution stage = conv_igemm_kernel (all instances: Winograd GEMMs + direct convolutions) + wino_gemm4_kernel + "
-                   "the Winograd transform kernels (wino_input / wino_output / wino_rows_in / wino_rows_out)",
+                   "the Winograd transform kernels (wino42_input / wino42_output / wino_input / wino_output / wino_rows_in / wino_rows_out)",
         "gfx950_correction": "FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",
         "hbm_bytes_per_step": tot,
         "per_kernel": per,
