@@ -125,16 +125,18 @@ def main():
             return pipe.collect_batch(submit())
         return [r["page"] for r in det.predict_batch(pages, _pages_dev=pages_dev, _maps_override=maps_dev)]
 
-    # detector-only workload (BASELINE configs[1]): groups of 2 pages on their own streams, two stream sets, the groups of step
-    # i+1 enqueued before step i's boxes are read back and filtered on the host
+    # detector-only workload (BASELINE configs[1]): groups of pages on their own streams, east_ahead + 1 stream sets, the groups of
+    # steps i+1 .. i+east_ahead enqueued before step i's boxes are read back and filtered on the host
     east_group = int(os.environ.get("MSOCR_EAST_GROUP", "4"))  # pages per detector launch sequence: 104 / 108 / 140 / 135 pages/s at 1 / 2 / 4 / 8
     east_bounds = [(lo, min(lo + east_group, NP)) for lo in range(0, NP, east_group)]
-    east_streams = [[torch.cuda.Stream() for _ in east_bounds] for _ in range(2)] if pipe is None else None
+    east_ahead = max(1, int(os.environ.get("MSOCR_EAST_AHEAD", "3")))  # steps enqueued ahead of the one being collected: 155-167 / 144-147 /
+    # 182-190 / 160-162 pages/s at 1 / 2 / 3 / 4 (3 ahead = 4 stream sets x 2 groups = the 8 hardware queues, one stream each)
+    east_streams = [[torch.cuda.Stream() for _ in east_bounds] for _ in range(east_ahead + 1)] if pipe is None else None
 
     def east_submit(i):
         main = torch.cuda.current_stream()
         hs = []
-        for st, (lo, hi) in zip(east_streams[i & 1], east_bounds):
+        for st, (lo, hi) in zip(east_streams[i % (east_ahead + 1)], east_bounds):
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 hs.append((st, lo, hi, det.detect_start(pages_dev[lo:hi], (maps_dev[0][lo:hi], maps_dev[1][lo:hi]))))
@@ -149,11 +151,11 @@ def main():
         return res
 
     def run_steps_east(k):
-        h, out_ = east_submit(0), None
+        q, out_ = [east_submit(j) for j in range(min(east_ahead, k))], None
         for i in range(k):
-            h_next = east_submit(i + 1) if i + 1 < k else None
-            out_ = east_collect(h)
-            h = h_next
+            if i + east_ahead < k:
+                q.append(east_submit(i + east_ahead))
+            out_ = east_collect(q.pop(0))
         return out_
 
     def run_steps(k):
