@@ -34,6 +34,7 @@ extern "C" {
 /* flags for msocr_conv2d */
 #define MSOCR_CONV_RELU 1u
 #define MSOCR_CONV_RESIDUAL 2u /* out = act(conv + bias + residual) */
+#define MSOCR_CONV_POOL2 4u    /* msocr_conv3x3_winograd42_fused only: out = maxpool2x2/2(act(conv + bias)), out is [N][H/2][W/2] */
 
 typedef struct msocr_conv_desc {
   int32_t dtype;                 /* MSOCR_F32 | MSOCR_BF16 (input, weight, residual, output) */
@@ -87,6 +88,19 @@ int msocr_winograd42_input_transform(const msocr_conv_desc* d, const void* in, v
 int msocr_winograd42_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream);
 int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
                                       void* out, void* stream);
+
+/* Cin == 64: the tall Winograd form with the 24 transform-domain GEMMs (K = 64) and the output transform fused in one kernel, so
+ * Mw never reaches HBM (unfused, a 64-channel layer is HBM-bound on Mw).  workspace holds V only
+ * (msocr_conv3x3_winograd42_fused_workspace_bytes; -1 = unsupported: Cin != 64, Cout % 32, or POOL2 with odd H / W or a residual).
+ * u_weight as for msocr_conv3x3_winograd42.  With MSOCR_CONV_POOL2 in d->flags the kernel also applies the 2x2 / stride-2 max-pool
+ * that follows conv0b of SE-ResNet31 (recognizers/_trba/model/seresnet31.py: conv0 -> MaxPool2d(2, 2)) and writes the pooled
+ * [N][H/2][W/2][Cout] map (d->out_ld = its channel stride).  msocr_winograd42_fused_gemm_output is stage 2 alone (stage 1 =
+ * msocr_winograd42_input_transform into the same workspace). */
+int64_t msocr_conv3x3_winograd42_fused_workspace_bytes(const msocr_conv_desc* d);
+int msocr_conv3x3_winograd42_fused(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                                   const void* residual, void* out, void* workspace, void* stream);
+int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, const float* u_weight, const void* workspace, const float* bias,
+                                       const void* residual, void* out, void* stream);
 
 /* The same convolution in the ROW-SPLIT Winograd form (csrc/winograd_rs.hip): the transforms are split by axis around a GEMM whose
  * workgroups own the 4 points of one transform row, so the arrays streamed through HBM are Q = (B^T d) (2x the input) and

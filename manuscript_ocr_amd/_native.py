@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsocr.so")
 
 F32, BF16 = 0, 1
-CONV_RELU, CONV_RESIDUAL = 1, 2
+CONV_RELU, CONV_RESIDUAL, CONV_POOL2 = 1, 2, 4
 
 c_i32, c_i64, c_u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
 c_f32, c_f64, c_vp = ctypes.c_float, ctypes.c_double, ctypes.c_void_p
@@ -54,6 +54,9 @@ _SIGS = {
     "msocr_winograd42_input_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_winograd42_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_winograd42_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd42_fused_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "msocr_conv3x3_winograd42_fused": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_winograd42_fused_gemm_output": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd_rs_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd_rs": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd_rs_rows_in": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),

@@ -369,6 +369,205 @@ extern "C" int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in
   return msocr_winograd42_output_transform(d, workspace, bias, residual, out, stream);
 }
 
+// =====================================================================================================================
+// Cin == 64: the tall form with the 24 GEMMs AND the output transform in ONE kernel (Mw never reaches HBM).
+// With 64 input channels the transform-domain GEMMs have K = 64 and the unfused form is HBM-bound on Mw (3x the layer's output:
+// TRBA conv0b would move 132 GB per step against 19 GB for the direct convolution).  Here a workgroup owns 32 tiles x 32 output
+// channels: for each of the 24 points it stages V[p][32 tiles][64] and U[p][32 couts][64] through LDS (double-buffered, 16-B chunks
+// XOR-swizzled by row), one 16x16 accumulator tile per wave and point (v_mfma_f32_16x16x4_f32, k = 64 -> 16 MFMAs); after the 24th
+// point every lane holds all 24 transform-domain values of its 4 (tile, cout) positions and applies A6^T . A4 in registers, then
+// bias / residual / ReLU and — MSOCR_CONV_POOL2 — the 2x2/2 max-pool that follows conv0b in SE-ResNet31 (seresnet31.py: conv0 ->
+// MaxPool2d(2,2)), so the pooled map is the only thing written.  HBM traffic: V once (3x the input) + the (pooled) output.
+// =====================================================================================================================
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void wino42_fused64_kernel(const float* __restrict__ V, const float* __restrict__ U, int Cout,
+                                                                 WinoGeom g, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, long res_ld, int relu,
+                                                                 float* __restrict__ out, long out_ld) {
+  constexpr int K = 64, BM = 32, BN = 32, ROWB = K * 4;  // 256-byte tile rows, 16 chunks of 16 B
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave >> 1, nj = wave & 1;
+  const int r16 = lane & 15, kg = lane >> 4;
+  // XCD-aware order: blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous range of logical blocks, cout blocks
+  // fastest, so the Cout/32 workgroups that read one V tile run on the same L2
+  const int nbn = Cout / BN;
+  const long nblk = (long)gridDim.x;
+  long bid = blockIdx.x;
+  {
+    const long q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int nb = (int)(bid % nbn);
+  const long m0 = (bid / nbn) * BM;
+  const int n0 = nb * BN;
+
+  // staging coordinates: thread -> (row = tid / 16 (+16 on the second pass), 16-B chunk = tid % 16)
+  const int chunk = tid & 15, row0 = tid >> 4;
+  const long planeV = g.Mt * (long)K, planeU = (long)Cout * K;
+  const float* pa[2];
+  const float* pb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    long m = m0 + row0 + 16 * i;
+    if (m >= g.Mt) m = g.Mt - 1;  // valid memory; the rows are never stored
+    pa[i] = V + m * K + chunk * 4;
+    pb[i] = U + (long)(n0 + row0 + 16 * i) * K + chunk * 4;
+  }
+  u32x4w ra[2], rb[2];
+  auto gload = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4w*>(pa[i] + p * planeV);
+      rb[i] = *reinterpret_cast<const u32x4w*>(pb[i] + p * planeU);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row0 + 16 * i;
+      *reinterpret_cast<u32x4w*>(&smem[buf][row * ROWB + ((chunk ^ (row & 15)) << 4)]) = ra[i];
+      *reinterpret_cast<u32x4w*>(&smem[buf][(BM + row) * ROWB + ((chunk ^ (row & 15)) << 4)]) = rb[i];
+    }
+  };
+  f32x4 acc[24];
+  gload(0);
+  sstore(0);
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 24; ++p) {
+    if (p + 1 < 24) gload(p + 1);  // global loads in flight under this point's MFMAs
+    const unsigned char* sa = &smem[p & 1][0];
+    const unsigned char* sb = sa + BM * ROWB;
+    // lane (r16, kg) takes k = 16 * kg + 0..15 of its row for BOTH operands (a consistent permutation of the reduction index)
+    const int rowa = mi * 16 + r16, rowb = nj * 16 + r16;
+    u32x4w fa[4], fb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = kg * 4 + q;
+      fa[q] = *reinterpret_cast<const u32x4w*>(sa + rowa * ROWB + ((c ^ (rowa & 15)) << 4));
+      fb[q] = *reinterpret_cast<const u32x4w*>(sb + rowb * ROWB + ((c ^ (rowb & 15)) << 4));
+    }
+    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[q][e]), __uint_as_float(fb[q][e]), c4, 0, 0, 0);
+    acc[p] = c4;
+    if (p + 1 < 24) sstore((p + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- output transform in registers: lane holds rows (tiles) 4 * kg + e, column (cout) r16 of its wave's 16x16 block ----
+  const int co = n0 + nj * 16 + r16;
+  const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long t = m0 + mi * 16 + 4 * kg + e;
+    if (t >= g.Mt) continue;
+    const int tw = (int)(t % g.TW);
+    const long r = t / g.TW;
+    const int th = (int)(r % g.TH);
+    const int n = (int)(r / g.TH);
+    float s[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float m0_ = acc[0 * 4 + j][e], m1 = acc[1 * 4 + j][e], m2 = acc[2 * 4 + j][e], m3 = acc[3 * 4 + j][e], m4 = acc[4 * 4 + j][e],
+                  m5 = acc[5 * 4 + j][e];
+      const float p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
+      s[0][j] = (m0_ + p12) + p34;
+      s[1][j] = d12 + 2.f * d34;
+      s[2][j] = p12 + 4.f * p34;
+      s[3][j] = (d12 + 8.f * d34) + m5;
+    }
+    float y[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y[i][0] = ((s[i][0] + s[i][1]) + s[i][2]) + b;
+      y[i][1] = ((s[i][1] - s[i][2]) - s[i][3]) + b;
+    }
+    if constexpr (POOL) {
+      // H and W are even (host check): the 2x2 windows are (rows 4th+{0,1} | 4th+{2,3}) x (cols 2tw+{0,1})
+      const int Hp = g.H >> 1, Wp = g.W >> 1;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int hp = 2 * th + i2;
+        if (hp >= Hp || tw >= Wp) continue;
+        float v0 = y[2 * i2][0], v1 = y[2 * i2][1], v2 = y[2 * i2 + 1][0], v3 = y[2 * i2 + 1][1];
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        out[(((long)n * Hp + hp) * Wp + tw) * out_ld + co] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ho = 4 * th + i;
+        if (ho >= g.H) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int wo = 2 * tw + j;
+          if (wo >= g.W) continue;
+          const long pix = ((long)n * g.H + ho) * g.W + wo;
+          float v = y[i][j];
+          if (res) v += res[pix * res_ld + co];
+          if (relu) v = fmaxf(v, 0.f);
+          out[pix * out_ld + co] = v;
+        }
+      }
+    }
+  }
+}
+
+static int wino42_fused_check(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino42_geom(d, g) || d->Cin != 64) return MSOCR_E_ARG;
+  if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  if (d->flags & MSOCR_CONV_POOL2) {
+    if ((d->H & 1) || (d->W & 1) || (d->flags & MSOCR_CONV_RESIDUAL)) return MSOCR_E_ARG;
+  }
+  return MSOCR_OK;
+}
+
+extern "C" int64_t msocr_conv3x3_winograd42_fused_workspace_bytes(const msocr_conv_desc* d) {
+  WinoGeom g;
+  if (wino42_fused_check(d, &g) != MSOCR_OK) return -1;
+  return 24 * g.Mt * (int64_t)d->Cin * (int64_t)sizeof(float);
+}
+
+// stage 2 of msocr_conv3x3_winograd42_fused (stage 1 is msocr_winograd42_input_transform): V in the workspace -> out
+extern "C" int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, const float* u_weight, const void* workspace,
+                                                  const float* bias, const void* residual, void* out, void* stream) {
+  WinoGeom g;
+  if (wino42_fused_check(d, &g) != MSOCR_OK || !u_weight || !workspace || !out) return MSOCR_E_ARG;
+  if (((uintptr_t)workspace | (uintptr_t)u_weight) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld < d->Cout)) return MSOCR_E_ARG;
+  const long nblk = ((g.Mt + 31) / 32) * (long)(d->Cout / 32);
+  if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
+  const int relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
+  if (d->flags & MSOCR_CONV_POOL2)
+    MSOCR_LAUNCH(wino42_fused64_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, u_weight,
+                 d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
+  else
+    MSOCR_LAUNCH(wino42_fused64_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, u_weight,
+                 d->Cout, g, bias, has_res ? (const float*)residual : nullptr, (long)d->res_ld, relu, (float*)out, (long)d->out_ld);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_conv3x3_winograd42_fused(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
+                                              const void* residual, void* out, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino42_fused_check(d, &g) != MSOCR_OK || !in || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const long nb_in = (g.Mt * (d->Cin / 4) + 255) / 256;
+  if (nb_in > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino42_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, (hipStream_t)stream, (const float*)in, (long)d->in_sN,
+               (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
+  if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+  return msocr_winograd42_fused_gemm_output(d, u_weight, workspace, bias, residual, out, stream);
+}
+
 // U[xi*4+nu][co][c] = sum_{kh,kw} G6[xi][kh] G4[nu][kw] w[co][kh][kw][c] (xi = 0..5 on the kernel's H axis), f64, rounded once.
 // HOST function like msocr_winograd_weights_host.
 extern "C" int msocr_winograd42_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {

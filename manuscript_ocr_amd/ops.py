@@ -109,11 +109,24 @@ def _tall_pays(H):
     return 24 * (-(-H // 4)) < 16 * (-(-H // 2))
 
 
+# Cin == 64 layers (TRBA conv0b, the 3x3s of ResNet-50 layer1): tall Winograd with the 24 GEMMs (K = 64) and the output transform
+# fused in one kernel (csrc/winograd.hip, wino42_fused64_kernel) — unfused, such a layer is HBM-bound on Mw.  conv2d(pool2=True)
+# folds the following 2x2/2 max-pool into the same kernel.  MSOCR_WINO_FUSED64=0 keeps these layers on the direct kernel.
+WINOGRAD_FUSED64 = int(os.environ.get("MSOCR_WINO_FUSED64", "1"))
+
+
 def attach_winograd(w):
     """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twins U = G g G^T ([16,Cout,Cin] f32 for F(2x2,3x3),
     [24,Cout,Cin] for the tall form F(4,3) x F(2,3); computed on the host in f64 by msocr_winograd[42]_weights_host).  conv2d() then
     takes the Winograd path for 3x3/1/1 calls."""
     Cout, KH, KW, Cin = w.shape
+    if (WINOGRAD_MIN_CIN and WINOGRAD_FUSED64 and WINOGRAD_TALL and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin == 64
+            and Cin < WINOGRAD_MIN_CIN and Cout % 32 == 0):
+        wh = w.detach().cpu().contiguous()
+        u42 = torch.empty((24, Cout, Cin), dtype=torch.float32)
+        nat.check(nat.lib().msocr_winograd42_weights_host(wh.data_ptr(), Cout, Cin, u42.data_ptr()), "winograd42_weights_host")
+        w._msocr_wino42_fused = u42.to(w.device)
+        return w
     if not (WINOGRAD_MIN_CIN and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin >= WINOGRAD_MIN_CIN and Cin % 16 == 0
             and Cout % 32 == 0):
         return w
@@ -127,9 +140,60 @@ def attach_winograd(w):
     return w
 
 
-def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None, alg_k=None):
+def _conv3x3_fused64(x, w, u42, bias, relu, residual, pool2, out):
+    """Cin == 64, 3x3/1/1, f32: tall Winograd, GEMMs + output transform (+ 2x2 max-pool) in one kernel."""
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    oh, ow = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        out = torch.empty((N, oh, ow, Cout), dtype=x.dtype, device=x.device)
+    assert out.shape == (N, oh, ow, Cout) and out.dtype == x.dtype
+    d = nat.ConvDesc()
+    d.dtype = _dt(x)
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.in_sN, d.in_sH, d.in_sW = x.stride(0), x.stride(1), x.stride(2)
+    d.KH, d.KW, d.stride_h, d.stride_w, d.pad_h, d.pad_w = 3, 3, 1, 1, 1, 1
+    d.Ho, d.Wo, d.Cout = H, W, Cout
+    d.out_ld = _pixel_dense_ld(out)
+    flags = (nat.CONV_RELU if relu else 0) | (nat.CONV_POOL2 if pool2 else 0)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype and not pool2
+        d.res_ld = _pixel_dense_ld(residual)
+        flags |= nat.CONV_RESIDUAL
+    d.flags = flags
+    L = nat.lib()
+    nbytes = L.msocr_conv3x3_winograd42_fused_workspace_bytes(ctypes.byref(d))
+    if nbytes < 0:
+        raise nat.NativeError(f"winograd42_fused: unsupported shape {tuple(x.shape)} * {tuple(w.shape)} pool2={pool2}")
+    parts = min(N, -(-nbytes // WINO_WS_LIMIT))
+    per = -(-N // parts)
+    ws = _wino_workspace(nbytes if parts == 1 else (nbytes // N) * per, x.device)
+    bp = bias.data_ptr() if bias is not None else None
+    what = f"msocr_conv3x3_winograd42_fused {tuple(x.shape)} * {tuple(w.shape)}"
+    TH, TW = (H + 3) // 4, (W + 1) // 2
+    alg = 2.0 * N * H * W * Cout * 9 * Cin
+    for n0 in range(0, N, per):
+        n1 = min(N, n0 + per)
+        d.N = n1 - n0
+        xp, rp_, op = x[n0:n1].data_ptr(), (residual[n0:n1].data_ptr() if residual is not None else None), out[n0:n1].data_ptr()
+        if PROFILE is None:
+            nat.check(L.msocr_conv3x3_winograd42_fused(ctypes.byref(d), xp, u42.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
+        else:
+            nn, mt = n1 - n0, (n1 - n0) * TH * TW
+            e = _prof_begin()
+            nat.check(L.msocr_winograd42_input_transform(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
+            _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + 24 * mt * Cin), (mt, Cin))
+            e = _prof_begin()
+            nat.check(L.msocr_winograd42_fused_gemm_output(ctypes.byref(d), u42.data_ptr(), ws.data_ptr(), bp, rp_, op, _stream()), what)
+            _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 24 * mt * Cin * Cout), (nn * H * W, Cout, 9 * Cin, "winograd42_fused"))
+    return out
+
+
+def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out=None, out_hw=None, alg_k=None, pool2=False):
     """x [N,H,W,Cin] (any N/H/W strides, channel stride 1), w [Cout,KH,KW,Cin], bias f32 [Cout] or None.
-    alg_k: algorithmic reduction length when the packed K is padded (stem), for FLOP accounting only."""
+    alg_k: algorithmic reduction length when the packed K is padded (stem), for FLOP accounting only.
+    pool2: return maxpool2x2/2 of the result (fused into the convolution where the fused Cin = 64 kernel applies, else a second
+    kernel)."""
     _need_cuda(x, w, bias, residual, out)
     N, H, W, Cin = x.shape
     Cout, KH, KW, Cw = w.shape
@@ -137,6 +201,12 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     sh, sw = stride
     ph, pw = pad
     Ho, Wo = out_hw if out_hw else ((H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1)
+    u42f = getattr(w, "_msocr_wino42_fused", None)
+    if (u42f is not None and WINOGRAD_FUSED64 and WINOGRAD_TALL and (sh, sw, ph, pw) == (1, 1, 1, 1) and (Ho, Wo) == (H, W)
+            and _tall_pays(H) and (not pool2 or (H % 2 == 0 and W % 2 == 0 and residual is None))):
+        return _conv3x3_fused64(x, w, u42f, bias, relu, residual, pool2, out)
+    if pool2:
+        return maxpool2d(conv2d(x, w, bias, stride, pad, relu, residual, None, out_hw, alg_k), 2, 2, 0, out=out)
     u = getattr(w, "_msocr_wino", None)
     use_wino = u is not None and (sh, sw, ph, pw) == (1, 1, 1, 1) and (Ho, Wo) == (H, W)
     if out is None:

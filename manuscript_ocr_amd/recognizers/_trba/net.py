@@ -126,8 +126,7 @@ class TrbaNet:
         x = ops.normalize_u8(canvases_u8, 1, 1, h + 2, w + 4, 1, self.dtype, cpad=self.cpad)
         ws, bs = self.P["stem"]
         x = ops.conv2d(stem_view(x, self.cin_pad), ws, bs, (1, 1), (0, 0), True, out_hw=(h, w), alg_k=27)
-        x = ops.conv2d(x, *self.P["conv0b"], pad=(1, 1), relu=True)
-        x = ops.maxpool2d(x, 2, 2, 0)
+        x = ops.conv2d(x, *self.P["conv0b"], pad=(1, 1), relu=True, pool2=True)  # conv0b + ReLU + MaxPool2d(2, 2)
         for lname, blocks, stride in LAYER_SPEC:
             for i in range(blocks):
                 x = self._se_block(x, lname, i, stride if i == 0 else 1)

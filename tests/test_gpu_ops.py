@@ -120,6 +120,71 @@ def test_conv3x3_winograd_vs_direct_and_f64(ops, case, form, monkeypatch):
     assert torch.all(big[..., :32] == 7.0)
 
 
+FUSED64_CASES = [
+    # N, H, W, Cout, relu, residual, pool2     (Cin = 64)
+    (3, 32, 100, 128, True, False, True),    # TRBA conv0b + MaxPool2d(2, 2)
+    (2, 16, 50, 128, True, False, True),
+    (1, 4, 6, 96, True, False, True),        # one tile row, 3 cout blocks
+    (2, 8, 12, 64, True, True, False),       # ResNet-50 layer1 style, residual
+    (1, 7, 9, 32, False, False, False),      # odd sizes: partial tiles, tiles not a multiple of the 32-tile workgroup
+    (5, 12, 11, 64, True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", FUSED64_CASES)
+def test_conv3x3_fused64_winograd_vs_direct_and_f64(ops, case):
+    """Cin = 64 layers: tall Winograd with GEMMs + output transform (+ 2x2 max-pool) fused in one kernel (wino42_fused64_kernel)
+    against an f64 convolution (+ residual, ReLU, max_pool2d): 2e-5 bound, within 8x of the direct kernel's own error; the
+    pooled result also equals max-pooling the kernel's own unpooled result exactly."""
+    N, H, W, Cout, relu, use_res, pool = case
+    Cin = 64
+    g = torch.Generator().manual_seed(sum(case[:4]) + 7)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    ref_full = ref
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
+    w_direct = _w_khwc(w, torch.float32)
+    w_f = ops.attach_winograd(_w_khwc(w, torch.float32))
+    assert getattr(w_f, "_msocr_wino42_fused", None) is not None and getattr(w_f, "_msocr_wino", None) is None
+    out_d = ops.conv2d(xd, w_direct, b.cuda(), (1, 1), (1, 1), relu, rd)
+    oh, ow = (H // 2, W // 2) if pool else (H, W)
+    big = torch.full((N, oh, ow, Cout + 32), 7.0, device="cuda")  # written into a channel slice
+    ops.conv2d(xd, w_f, b.cuda(), (1, 1), (1, 1), relu, rd, out=big[..., 32:], pool2=pool)
+    full = ops.conv2d(xd, w_f, b.cuda(), (1, 1), (1, 1), relu, rd)  # same kernel, no pooling
+    torch.cuda.synchronize()
+    scale = max(ref_full.abs().max().item(), 1.0)
+    e_d = (out_d.cpu().permute(0, 3, 1, 2).double() - ref_full).abs().max().item()
+    got = big[..., 32:].cpu().permute(0, 3, 1, 2)
+    e_w = (got.double() - ref).abs().max().item()
+    assert e_w <= 2e-5 * scale and e_w <= 8 * e_d + 1e-6 * scale, (e_w, e_d, scale)
+    assert torch.all(big[..., :32] == 7.0)
+    if pool:
+        assert torch.equal(got, F.max_pool2d(full.cpu().permute(0, 3, 1, 2), 2, 2))
+
+
+def test_conv_pool2_unfused_paths(ops):
+    """pool2=True where the fused kernel does not apply (Cin = 128 Winograd layer; Cin = 64 with an odd width): convolution followed
+    by the max-pool kernel, same result as the two calls made by hand."""
+    g = torch.Generator().manual_seed(3)
+    for Cin, H, W in ((128, 8, 12), (64, 8, 11)):
+        x = _to_nhwc(torch.randn(2, Cin, H, W, generator=g), torch.float32)
+        w = ops.attach_winograd(_w_khwc(torch.randn(64, Cin, 3, 3, generator=g) * 0.05, torch.float32))
+        b = torch.randn(64, generator=g).cuda()
+        a = ops.conv2d(x, w, b, (1, 1), (1, 1), True, pool2=True)
+        c = ops.maxpool2d(ops.conv2d(x, w, b, (1, 1), (1, 1), True), 2, 2, 0)
+        torch.cuda.synchronize()
+        assert a.shape == (2, H // 2, W // 2, 64) and torch.equal(a, c)
+
+
 def test_winograd_weight_transform_matches_definition(ops):
     """U = G g G^T evaluated in f64 (msocr_winograd_weights_host) for every (xi, nu)."""
     g = torch.Generator().manual_seed(9)
