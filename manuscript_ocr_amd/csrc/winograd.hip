@@ -380,9 +380,12 @@ extern "C" int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in
 // MaxPool2d(2,2)), so the pooled map is the only thing written.  HBM traffic: V once (3x the input) + the (pooled) output.
 // =====================================================================================================================
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+#ifndef WINO_FUSED_PFD
+#define WINO_FUSED_PFD 3
+#endif
 
 template <bool POOL>
-__global__ __launch_bounds__(256, 2) void wino42_fused64_kernel(const float* __restrict__ V, const float* __restrict__ U, int Cout,
+__global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __restrict__ V, const float* __restrict__ U, int Cout,
                                                                  WinoGeom g, const float* __restrict__ bias,
                                                                  const float* __restrict__ res, long res_ld, int relu,
                                                                  float* __restrict__ out, long out_ld) {
@@ -416,29 +419,32 @@ __global__ __launch_bounds__(256, 2) void wino42_fused64_kernel(const float* __r
     pa[i] = V + m * K + chunk * 4;
     pb[i] = U + (long)(n0 + row0 + 16 * i) * K + chunk * 4;
   }
-  u32x4w ra[2], rb[2];
+  // register prefetch PFD points ahead (slot = point % PFD): one point's MFMAs (16 per wave) are shorter than an HBM round trip
+  constexpr int PFD = WINO_FUSED_PFD;
+  u32x4w ra[PFD][2], rb[PFD][2];
   auto gload = [&](int p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ra[i] = *reinterpret_cast<const u32x4w*>(pa[i] + p * planeV);
-      rb[i] = *reinterpret_cast<const u32x4w*>(pb[i] + p * planeU);
+      ra[p % PFD][i] = *reinterpret_cast<const u32x4w*>(pa[i] + p * planeV);
+      rb[p % PFD][i] = *reinterpret_cast<const u32x4w*>(pb[i] + p * planeU);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = row0 + 16 * i;
-      *reinterpret_cast<u32x4w*>(&smem[buf][row * ROWB + ((chunk ^ (row & 15)) << 4)]) = ra[i];
-      *reinterpret_cast<u32x4w*>(&smem[buf][(BM + row) * ROWB + ((chunk ^ (row & 15)) << 4)]) = rb[i];
+      *reinterpret_cast<u32x4w*>(&smem[p & 1][row * ROWB + ((chunk ^ (row & 15)) << 4)]) = ra[p % PFD][i];
+      *reinterpret_cast<u32x4w*>(&smem[p & 1][(BM + row) * ROWB + ((chunk ^ (row & 15)) << 4)]) = rb[p % PFD][i];
     }
   };
   f32x4 acc[24];
-  gload(0);
+#pragma unroll
+  for (int q = 0; q < PFD; ++q) gload(q);
   sstore(0);
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < 24; ++p) {
-    if (p + 1 < 24) gload(p + 1);  // global loads in flight under this point's MFMAs
+    if (p + PFD < 24) gload(p + PFD);  // slot p % PFD held point p, stored to LDS at the end of point p - 1
     const unsigned char* sa = &smem[p & 1][0];
     const unsigned char* sb = sa + BM * ROWB;
     // lane (r16, kg) takes k = 16 * kg + 0..15 of its row for BOTH operands (a consistent permutation of the reduction index)
@@ -450,6 +456,8 @@ __global__ __launch_bounds__(256, 2) void wino42_fused64_kernel(const float* __r
       fa[q] = *reinterpret_cast<const u32x4w*>(sa + rowa * ROWB + ((c ^ (rowa & 15)) << 4));
       fb[q] = *reinterpret_cast<const u32x4w*>(sb + rowb * ROWB + ((c ^ (rowb & 15)) << 4));
     }
+    // one dependent accumulation chain per point (two chains double the live registers: measured, dropped; the U fragments straight
+    // from L2 instead of LDS: 1.5x slower)
     f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void wino42_fused64_kernel(const float* __r
       for (int e = 0; e < 4; ++e)
         c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[q][e]), __uint_as_float(fb[q][e]), c4, 0, 0, 0);
     acc[p] = c4;
-    if (p + 1 < 24) sstore((p + 1) & 1);
+    if (p + 1 < 24) sstore(p + 1);
     __syncthreads();
   }
 
