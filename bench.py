@@ -422,8 +422,13 @@ def pmc_traffic():
     for path in reversed(paths):
         try:
             with open(path) as f:
-                return {"hbm_bytes_per_step": float(json.load(f)["hbm_bytes_per_step"]), "source": os.path.relpath(path, ROOT),
-                        "measured_in_this_run": False}
+                d = json.load(f)
+            out = {"hbm_bytes_per_step": float(d["hbm_bytes_per_step"]), "source": os.path.relpath(path, ROOT),
+                   "measured_in_this_run": False}
+            st = (d.get("mfma_pmc") or {}).get("conv_stage")
+            if st:  # SQ_VALU_MFMA_BUSY_CYCLES over the stage's kernels (GEMMs + transforms), launches one at a time
+                out["conv_stage_mfma_pipe_busy_fraction"] = float(st["mfma_pipe_busy_fraction"])
+            return out
         except Exception:
             continue
     return None

@@ -78,7 +78,14 @@ def main():
                          "mfma_pipe_busy_fraction": busy[n][1] / (gui[n][1] / 8.0 * 1024.0),   # 1024 SIMDs, GUI summed over 8 XCDs
                          "clock_ghz": gui[n][1] / 8.0 / gui[n][2],
                          "executed_mfma_tflops": busy[n][1] * 64.0 / (gui[n][2] * 1e-9) / 1e12}  # 64 FLOP/clk/SIMD (f32 MFMA)
-        res["mfma_pmc"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py "
+        # the whole convolution stage (GEMM kernels AND the Winograd transforms, which run no MFMA), launches one at a time:
+        # north_star's "MFMA utilisation of the conv stages"
+        sb = sum(busy[n][1] for n in busy if n.startswith(CONV_STAGE))
+        sg = sum(gui[n][1] for n in gui if n.startswith(CONV_STAGE))
+        sn = sum(gui[n][2] for n in gui if n.startswith(CONV_STAGE))
+        stage = {"mfma_pipe_busy_fraction": sb / (sg / 8.0 * 1024.0), "clock_ghz": sg / 8.0 / sn,
+                 "executed_mfma_tflops": sb * 64.0 / (sn * 1e-9) / 1e12, "kernel_ns_per_step": sn / steps}
+        res["mfma_pmc"] = {"conv_stage": stage, "command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py "
                                       "--no-cpu-baseline --no-roofline --serialize-streams --steps 1 --warmup 1", "per_kernel": mm}
     with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(res, fh, indent=1)
