@@ -364,3 +364,22 @@ def test_vectorised_crop_descriptors_equal_the_loop():
             assert np.array_equal(k1, k2) and d1.dtype == d2.dtype and np.array_equal(d1, d2)
     d, k = ops.crop_descriptors([], [], (100, 100), 32, 100)
     assert d.shape == (0, 8) and k.shape == (0,)
+
+
+def test_winograd_weight_transforms_host():
+    """The two load-time weight transforms are HOST functions of the C ABI (f64, rounded once): U = G g G^T for F(2x2,3x3) and
+    U = G6 g G4^T for the tall form F(4,3) x F(2,3), checked against their definitions without a GPU."""
+    from manuscript_ocr_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(11)
+    Cout, Cin = 32, 16
+    w = rng.standard_normal((Cout, 3, 3, Cin)).astype(np.float32)  # [Cout][KH][KW][Cin]
+    G4 = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float64)
+    G6 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]], np.float64)
+    for fn, Gh, npts in ((L.msocr_winograd_weights_host, G4, 16), (L.msocr_winograd42_weights_host, G6, 24)):
+        u = np.empty((npts, Cout, Cin), np.float32)
+        assert fn(w.ctypes.data, Cout, Cin, u.ctypes.data) == 0
+        exp = np.einsum("xk,oklc,nl->xnoc", Gh, w.astype(np.float64), G4).reshape(npts, Cout, Cin)
+        assert np.abs(u.astype(np.float64) - exp).max() <= 1.2e-7 * np.abs(exp).max()
+    assert L.msocr_winograd42_weights_host(None, Cout, Cin, None) != 0
