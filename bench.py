@@ -56,9 +56,90 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay the detector's and the recogniser's launch sequences from hipGraphs (BASELINE configs[3] wording; "
                          "DESIGN.md 7 has the A/B against plain launches)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the three rocprofv3 --pmc child runs that measure roofline.traffic (FETCH_SIZE, WRITE_SIZE) and the MFMA-pipe utilisation for this line")
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the sub-batch pipeline on ONE stream (no cross-stream kernel overlap): per-kernel profiling mode")
     return ap.parse_args()
+
+
+CONV_STAGE_KERNELS = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel",
+                      "wino42_fused64_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+
+
+def live_pmc_traffic(a):
+    """roofline.traffic (and the MFMA-pipe utilisation), measured for THIS invocation: HBM bytes per step of the convolution stage from the PMC counters, collected
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc`
+    passes (they do not fit one), FETCH_SIZE doubled on gfx950 (wide coalesced reads are counted at 64 B per 128-B request), both in
+    KiB.  Each pass is a CHILD process running this same workload for 4 steps (2 priming + 1 warm-up + 1 timed); the children run
+    BEFORE this process touches the GPU, so nothing of them overlaps the timed region.  Returns (dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-roofline", "--no-live-traffic", "--steps", "1",
+           "--warmup", "1", "--workload", a.workload, "--precision", a.precision, "--height", str(a.height), "--width", str(a.width)]
+    for flag, val in (("--pages", a.pages), ("--target-size", a.target_size), ("--sub-batches", a.sub_batches)):
+        if val:
+            cmd += [flag, str(val)]
+    if a.graphs:
+        cmd.append("--graphs")
+    steps = 4.0
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+        d = tempfile.mkdtemp(prefix="msocr_pmc_", dir="/tmp")
+        try:
+            extra = ["--serialize-streams"] if " " in counter else []
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counter.split() + ["--output-format", "csv", "-d", d, "--"] + cmd
+                               + extra, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, timeout=900)
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            per = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    n = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+                    if not n.startswith(CONV_STAGE_KERNELS):
+                        continue
+                    n = n.split("<")[0]
+                    if " " not in counter:
+                        if row["Counter_Name"] == counter:
+                            per[n] = per.get(n, 0.0) + float(row["Counter_Value"])
+                    else:  # [busy cycles, active cycles summed over XCDs, kernel ns]
+                        e = per.setdefault(n, [0.0, 0.0, 0])
+                        if row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                            e[0] += float(row["Counter_Value"])
+                        elif row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                            e[1] += float(row["Counter_Value"])
+                            e[2] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            kib[counter] = per
+        except Exception as e:  # noqa: BLE001 — the bench line must still be printed
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    names = sorted(set(kib["FETCH_SIZE"]) | set(kib["WRITE_SIZE"]))
+    per_kernel = {n: (2.0 * kib["FETCH_SIZE"].get(n, 0.0) + kib["WRITE_SIZE"].get(n, 0.0)) * 1024.0 / steps for n in names}
+    mf = kib.get("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE")
+    mfma = None
+    if mf:  # third pass, launches one at a time (--serialize-streams): matrix-pipe busy cycles / (active cycles x 1024 SIMDs)
+        def util(pred):
+            b = sum(v[0] for n, v in mf.items() if pred(n))
+            g = sum(v[1] for n, v in mf.items() if pred(n))
+            ns = sum(v[2] for n, v in mf.items() if pred(n))
+            return {"mfma_pipe_busy_fraction": b / (g / 8.0 * 1024.0), "clock_ghz": g / 8.0 / ns,
+                    "executed_mfma_tflops": b * 64.0 / (ns * 1e-9) / 1e12, "kernel_ms_per_step": ns / steps / 1e6} if g > 0 else None
+        mfma = {"conv_stage": util(lambda n: True),
+                "gemm_kernels": util(lambda n: n.startswith(("conv_igemm_kernel", "wino42_fused64_kernel", "wino_gemm4_kernel"))),
+                "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 x 1024 SIMDs), one rocprofv3 --pmc "
+                            "pass with --serialize-streams; conv_stage = GEMM kernels + Winograd transforms, gemm_kernels = without them"}
+    return {"hbm_bytes_per_step": sum(per_kernel.values()), "per_kernel_bytes_per_step": per_kernel, "mfma_pmc": mfma,
+            "counters": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB, separate rocprofv3 --kernel-trace --pmc passes of this "
+                        "workload (4 steps each), convolution-stage kernels only", "measured_in_this_run": True}, "ok"
 
 
 def main():
@@ -68,6 +149,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    live_traffic, live_note = None, "not requested"
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)  # no profiler inside a profiled run
+    if world == 1 and not (a.no_live_traffic or a.no_roofline or a.serialize_streams or under_profiler) and a.precision == "fp32":
+        t_pmc = time.time()
+        live_traffic, live_note = live_pmc_traffic(a)  # child processes; this process has not touched the GPU yet
+        print(f"[bench] live PMC traffic passes: {live_note}, {time.time() - t_pmc:.0f} s", file=sys.stderr)
     torch.cuda.set_device(local)
     # Native libraries (RCCL prints a version banner) write to the process's stdout; the contract is ONE JSON line there.
     # Keep the real stdout for that line and point fd 1 at stderr for everything else.
@@ -340,7 +427,8 @@ def main():
             "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": executed / (gemm_ms * 1e-3) / 1e12 / peak,
                                  "busy_ms_per_step": gemm_ms / a.steps},
             "algorithmic_equiv_tflops": algorithmic / (stage_ms * 1e-3) / 1e12,
-            "traffic": None,
+            "traffic": live_traffic,
+            "traffic_note": live_note,
             "traffic_from_profile": pmc_traffic() if (a.workload == "pipeline" and a.precision == "fp32" and not a.pages
                                                       and not a.sub_batches) else None,
             "launches_per_step": len(gemm) // a.steps,
