@@ -93,8 +93,10 @@ __device__ __forceinline__ int swz(int row) {
 // WPE: workgroups per CU the register allocation is held to (0 = 3 for the one-stage 128-byte-row form, else 2); STAG: stagger
 // the start of every third workgroup of a CU's share by part of a K-tile so that co-resident workgroups do not run their
 // barrier / staging phases in lockstep (diagnostic variants, MSOCR_GEMM_VARIANT).
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0,
+          bool DIRECT = false>
 __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 : 2)) void conv_igemm_kernel(ConvParams p) {
+  static_assert(!DIRECT || (MT == 16 && sizeof(T) == 4), "direct epilogue: f32 16x16x4 tiles");
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
   constexpr int EPC = 16 / ES;   // elements per chunk
@@ -265,7 +267,10 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[i][j], 0, 0, 0);
+              if constexpr (DIRECT)  // transposed tile: the lane's 4 accumulators are 4 consecutive output channels of one row
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[j][e]), __uint_as_float(fa[i][e]), acc[i][j], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[i][j], 0, 0, 0);
       }
     } else {
     u32x4 fa[2][TM], fb[2][TN];
@@ -303,6 +308,25 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
     __syncthreads();
   }
 
+  if constexpr (DIRECT) {
+    // ---- direct epilogue: no LDS round trip, no barriers.  acc[i][j] = D[n = 4 * half + e][m = r32] of the (i, j) 16x16 tile, so a
+    // lane stores 16 bytes (4 consecutive output channels) of row m; the TN tiles of a wave fill 64 contiguous bytes per row each ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = (long)tile_m * BM + wm * WM + i * MT + r32;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = tile_n * BN + wn * WN + j * MT + 4 * half;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+        if (p.has_res) v += *reinterpret_cast<const f32x4*>(p.res + (m * p.res_ld + co) * ES);
+        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(g_out + (m * p.out_ld + co) * ES) = v;
+      }
+    }
+    return;
+  }
   // ---- epilogue: TM passes of (acc row-block -> LDS [PR][BN] f32 -> bias/residual/ReLU -> 16-B stores) ----
   constexpr int PR = (BM / WM) * 32;  // tile rows handled per pass
   float* sc = reinterpret_cast<float*>(smem);
@@ -368,7 +392,8 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0,
+          bool DIRECT = false>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -376,9 +401,9 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.cin_tiles = p.Cin / BK;
   p.ktiles = p.KH * p.KW * p.cin_tiles;
   constexpr int STAGE = (BM + BN) * BKB;
-  constexpr int EPI = (BM / WM) * 32 * BN * 4;
+  constexpr int EPI = DIRECT ? 0 : (BM / WM) * 32 * BN * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT, WPE, STAG>;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT, WPE, STAG, DIRECT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -416,6 +441,9 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
         if (gv == 3) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 3, 8>(p, s);                          // staggered start
         if (gv == 4) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 4>(p, s);                             // 4 per CU (128 VGPRs)
         if (gv == 5) return launch_cfg<T, 128, 128, 128, 64, 64, 2, true, 16, 2>(p, s);                             // two LDS stages, 2 per CU
+        if (gv == 6) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4, 0, true>(p, s);                     // as 2, direct epilogue
+        if (gv == 7 && p.Ktot <= 256) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4, 0, true>(p, s);    // direct epilogue at short K only
+        if (gv == 7) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);
         return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16>(p, s);
       }
       if (wide && variant == 1 && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
