@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256) void attn_greedy_kernel(AttnArgs a) {
   }
 }
 
+// DIAGNOSTIC kernel (MSOCR_BEAM_MFMA=0), off the default path: the default beam decoder is attn_beam_mfma_kernel (attn_beam_mfma.hip);
+// this VALU form stays as its independent cross-check (tests/test_gpu_trba.py: MFMA vs VALU agreement, three-way parity test).
 // HB = number of 256-thread halves per workgroup.  With HB = 2 two batch rows share one workgroup: both halves run
 // the same instruction stream between the same barriers, so the second half's weight loads hit the lines the first
 // half just pulled into the CU's L1 — the L2 -> L1 weight stream that bounds this kernel is paid once for two rows,

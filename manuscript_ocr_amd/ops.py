@@ -484,7 +484,8 @@ def crop_descriptors(boxes, page_ids, page_hw, img_h, img_w):
 
 
 def _crop_descriptors_loop(boxes, page_ids, page_hw, img_h, img_w):
-    """Literal per-box form of `crop_descriptors` (kept for the differential CPU test)."""
+    """DIAGNOSTIC, not on any product path: the literal per-box form of `crop_descriptors`, kept only as the second implementation
+    of the differential CPU test (tests/test_host_cpu.py::test_vectorised_crop_descriptors_equal_the_loop)."""
     import numpy as np
     H, W = page_hw
     desc, keep = [], []
