@@ -383,3 +383,51 @@ def test_winograd_weight_transforms_host():
         exp = np.einsum("xk,oklc,nl->xnoc", Gh, w.astype(np.float64), G4).reshape(npts, Cout, Cin)
         assert np.abs(u.astype(np.float64) - exp).max() <= 1.2e-7 * np.abs(exp).max()
     assert L.msocr_winograd42_weights_host(None, Cout, Cin, None) != 0
+
+
+def test_bench_live_pmc_digest_with_a_stub_profiler(tmp_path, monkeypatch):
+    """bench.live_pmc_traffic: the three `rocprofv3 --kernel-trace --pmc ...` child passes are parsed as MI355X_MICROARCH.md
+    prescribes (2 x FETCH_SIZE + WRITE_SIZE KiB per step, conv-stage kernels only; MFMA busy / (active / 8 x 1024)).  The profiler is a
+    stub script here (no GPU): it writes the counter CSV rocprofv3 would write."""
+    import argparse
+    import importlib.util
+    import stat
+    stub = tmp_path / "rocprofv3"
+    stub.write_text(r'''#!/bin/bash
+out=""; pmc=""
+while [ $# -gt 0 ]; do
+  case "$1" in
+    -d) out="$2"; shift 2;;
+    --pmc) shift; while [ $# -gt 0 ] && [[ "$1" != --* ]]; do pmc="$pmc $1"; shift; done;;
+    --) break;;
+    *) shift;;
+  esac
+done
+mkdir -p "$out/host"
+f="$out/host/1_counter_collection.csv"
+echo '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"' > "$f"
+row() { echo "1,1,1,1,1,1,1,1,\"$1\",256,0,0,0,0,0,\"$2\",$3,$4,$5" >> "$f"; }
+for c in $pmc; do
+  case "$c" in
+    FETCH_SIZE) row "void conv_igemm_kernel<float, 128>(ConvParams)" FETCH_SIZE 4000 0 10; row "wino42_input_kernel(float const*)" FETCH_SIZE 1000 0 10; row "other_kernel(int)" FETCH_SIZE 99999 0 10;;
+    WRITE_SIZE) row "void conv_igemm_kernel<float, 128>(ConvParams)" WRITE_SIZE 2000 0 10; row "wino42_input_kernel(float const*)" WRITE_SIZE 3000 0 10;;
+    SQ_VALU_MFMA_BUSY_CYCLES) row "void conv_igemm_kernel<float, 128>(ConvParams)" SQ_VALU_MFMA_BUSY_CYCLES 512000 0 1000; row "wino42_input_kernel(float const*)" SQ_VALU_MFMA_BUSY_CYCLES 0 0 1000;;
+    GRBM_GUI_ACTIVE) row "void conv_igemm_kernel<float, 128>(ConvParams)" GRBM_GUI_ACTIVE 8000 0 1000; row "wino42_input_kernel(float const*)" GRBM_GUI_ACTIVE 8000 2000 3000;;
+  esac
+done
+exit 0
+''')
+    stub.chmod(stub.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = argparse.Namespace(workload="pipeline", precision="fp32", height=64, width=64, pages=0, target_size=0, sub_batches=0, graphs=False)
+    res, note = bench.live_pmc_traffic(a)
+    assert note == "ok" and res["measured_in_this_run"] is True
+    per = res["per_kernel_bytes_per_step"]
+    assert per["conv_igemm_kernel"] == (2 * 4000 + 2000) * 1024 / 4 and per["wino42_input_kernel"] == (2 * 1000 + 3000) * 1024 / 4
+    assert res["hbm_bytes_per_step"] == sum(per.values()) and "other_kernel" not in per
+    m = res["mfma_pmc"]
+    assert abs(m["gemm_kernels"]["mfma_pipe_busy_fraction"] - 512000 / (8000 / 8 * 1024)) < 1e-12
+    assert abs(m["conv_stage"]["mfma_pipe_busy_fraction"] - 512000 / (16000 / 8 * 1024)) < 1e-12
