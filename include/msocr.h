@@ -93,7 +93,7 @@ int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* work
  * Mw never reaches HBM (unfused, a 64-channel layer is HBM-bound on Mw).  workspace holds V only
  * (msocr_conv3x3_winograd42_fused_workspace_bytes; -1 = unsupported: Cin != 64, Cout % 32, or POOL2 with odd H / W or a residual).
  * u_weight as for msocr_conv3x3_winograd42.  With MSOCR_CONV_POOL2 in d->flags the kernel also applies the 2x2 / stride-2 max-pool
- * that follows conv0b of SE-ResNet31 (recognizers/_trba/model/seresnet31.py: conv0 -> MaxPool2d(2, 2)) and writes the pooled
+ * that closes conv0 of SE-ResNet31 (recognizers/_trba/model/seresnet31.py:81-89: conv3x3 64->128, BN, ReLU, MaxPool2d(2, 2)) and writes the pooled
  * [N][H/2][W/2][Cout] map (d->out_ld = its channel stride).  msocr_winograd42_fused_gemm_output is stage 2 alone (stage 1 =
  * msocr_winograd42_input_transform into the same workspace). */
 int64_t msocr_conv3x3_winograd42_fused_workspace_bytes(const msocr_conv_desc* d);

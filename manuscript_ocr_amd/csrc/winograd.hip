@@ -376,8 +376,8 @@ extern "C" int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in
 // channels: for each of the 24 points it stages V[p][32 tiles][64] and U[p][32 couts][64] through LDS (double-buffered, 16-B chunks
 // XOR-swizzled by row), one 16x16 accumulator tile per wave and point (v_mfma_f32_16x16x4_f32, k = 64 -> 16 MFMAs); after the 24th
 // point every lane holds all 24 transform-domain values of its 4 (tile, cout) positions and applies A6^T . A4 in registers, then
-// bias / residual / ReLU and — MSOCR_CONV_POOL2 — the 2x2/2 max-pool that follows conv0b in SE-ResNet31 (seresnet31.py: conv0 ->
-// MaxPool2d(2,2)), so the pooled map is the only thing written.  HBM traffic: V once (3x the input) + the (pooled) output.
+// bias / residual / ReLU and — MSOCR_CONV_POOL2 — the 2x2/2 max-pool that closes conv0 in SE-ResNet31 (seresnet31.py:81-89: ... ReLU,
+// MaxPool2d(2, 2)), so the pooled map is the only thing written.  HBM traffic: V once (3x the input) + the (pooled) output.
 // =====================================================================================================================
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 #ifndef WINO_FUSED_PFD
