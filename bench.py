@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay the detector's and the recogniser's launch sequences from hipGraphs (BASELINE configs[3] wording; "
                          "DESIGN.md 7 has the A/B against plain launches)")
+    ap.add_argument("--host-pages", action="store_true",
+                    help="hand the pages over as HOST arrays every step, as Pipeline.predict()'s callers do (PCIe-inclusive rate, "
+                         "DESIGN.md 7); the default keeps the synthetic pages resident in HBM as the bench contract asks")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the three rocprofv3 --pmc child runs that measure roofline.traffic (FETCH_SIZE, WRITE_SIZE) and the MFMA-pipe utilisation for this line")
     ap.add_argument("--serialize-streams", action="store_true",
@@ -205,7 +208,8 @@ def main():
     maps_dev = (torch.from_numpy(np.stack(scores)).cuda(), torch.from_numpy(np.stack(geos)).cuda())
 
     def submit():
-        return pipe.submit_batch(pages, pages_dev=pages_dev, sub_batches=a.sub_batches, _maps_override=maps_dev)
+        return pipe.submit_batch(pages, pages_dev=None if a.host_pages else pages_dev, sub_batches=a.sub_batches,
+                                 _maps_override=maps_dev)
 
     def step():
         if pipe is not None:
@@ -339,7 +343,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16"}[a.precision],
-        "data": "synthetic",
+        "data": "synthetic" + (", host pages uploaded every step (PCIe-inclusive)" if a.host_pages else ""),
         "config": {
             "workload": (f"full EAST->crop->TRBA pipeline (BASELINE configs[3]): batch={NP} pages @ {W}x{H} per GPU, "
                          + (f"native network input {H}x{W}" if not a.target_size else f"pages resized to {TW}x{TH} on the device") +
