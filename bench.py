@@ -431,8 +431,13 @@ def main():
             "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": executed / (gemm_ms * 1e-3) / 1e12 / peak,
                                  "busy_ms_per_step": gemm_ms / a.steps},
             "algorithmic_equiv_tflops": algorithmic / (stage_ms * 1e-3) / 1e12,
-            "traffic": live_traffic,
+            # HBM bytes per step of the convolution stage, PMC counters of this invocation (live_pmc_traffic); null if not measured
+            "traffic": live_traffic["hbm_bytes_per_step"] if live_traffic else None,
+            "traffic_unit": "bytes per step, convolution-stage kernels (2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction)",
             "traffic_note": live_note,
+            "traffic_detail": ({k: live_traffic[k] for k in ("per_kernel_bytes_per_step", "counters", "measured_in_this_run")}
+                               if live_traffic else None),
+            "mfma_pmc": live_traffic["mfma_pmc"] if live_traffic else None,
             "traffic_from_profile": pmc_traffic() if (a.workload == "pipeline" and a.precision == "fp32" and not a.pages
                                                       and not a.sub_batches) else None,
             "launches_per_step": len(gemm) // a.steps,
