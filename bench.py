@@ -456,6 +456,16 @@ def main():
                                        "avg_launch_ms": float(dur.mean()), "gemm_ms_per_step": float(dur.sum() / a.steps),
                                        "conv_stage_ms_per_step": float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])) / a.steps)}
         HBM_PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
+        # the stage priced kernel by kernel at each kernel's OWN bound: GEMM launches at the f32 MFMA peak on the FLOP they execute,
+        # Winograd transforms at the HBM peak on their algorithmic bytes — the floor of the stage's time with this algorithm mix
+        tr_bytes = float(sum(w for k in ("wino_in", "wino_out") for _, _, w, _ in by.get(k, [])))
+        floor_ms = (ex2 / (peak * 1e12) + tr_bytes / (HBM_PEAK * 1e9)) * 1e3
+        iso_ms = float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])))
+        res["roofline"]["mixed_bound"] = {
+            "floor_ms_per_step": floor_ms / a.steps, "frac_isolated": floor_ms / iso_ms, "frac": floor_ms / stage_ms,
+            "transform_gbytes_per_step": tr_bytes / a.steps / 1e9,
+            "definition": "floor = executed GEMM FLOP / 157.3 TFLOP/s + algorithmic bytes of the Winograd transforms / 8 TB/s; frac = floor / "
+                          "conv-stage-busy time of the overlapped run, frac_isolated = floor / summed isolated launch durations"}
         names = {"wino_in": "wino42_input_kernel", "wino_out": "wino42_output_kernel", "se_residual": "se_residual_kernel",
                  "maxpool": "maxpool_kernel", "bilstm": "bilstm_kernel", "attn_beam": "attn_beam_mfma_kernel"}
         mean_run = (rec.last_run_length_sum / rec.last_rows) if (rec is not None and getattr(rec, "last_rows", 0)) else None
