@@ -99,7 +99,7 @@ def live_pmc_traffic(a):
             extra = ["--serialize-streams"] if " " in counter else []
             r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counter.split() + ["--output-format", "csv", "-d", d, "--"] + cmd
                                + extra, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE, timeout=900)
+                               stderr=subprocess.PIPE, timeout=300)
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
