@@ -97,12 +97,20 @@ def live_pmc_traffic(a):
         d = tempfile.mkdtemp(prefix="msocr_pmc_", dir="/tmp")
         try:
             extra = ["--serialize-streams"] if " " in counter else []
-            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counter.split() + ["--output-format", "csv", "-d", d, "--"] + cmd
-                               + extra, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE, timeout=300)
+            # own session: the profiler starts the workload as a grandchild; a pass that overruns is killed as a group
+            proc = subprocess.Popen([exe, "--kernel-trace", "--pmc"] + counter.split() + ["--output-format", "csv", "-d", d, "--"] + cmd
+                                    + extra, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter}: no result within 300 s (killed)"
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            if proc.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
             per = {}
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
