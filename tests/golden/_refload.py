@@ -100,3 +100,108 @@ def ref_trba_model():
 
 def ref_types():
     return load_file("ref_types", "detectors/_types.py")
+
+
+# ---- package-style loads (files that use relative imports) -------------------------------------
+# A synthetic package tree "refman" mirrors the reference's package names; every node is an EMPTY
+# module with a __path__ (so `from .x import y` resolves through sys.modules), the files on the hot
+# path are executed from where they lie under /root/reference, and the training-only siblings they
+# import at module level (dataset, train_utils, training.train) are inert stubs holding None names.
+
+def _pkg(name, relpath):
+    if name in sys.modules:
+        return sys.modules[name]
+    m = types.ModuleType(name)
+    m.__path__ = [str(REF / relpath)] if relpath is not None else []
+    m.__package__ = name
+    sys.modules[name] = m
+    return m
+
+
+class _Inert:
+    """Base class / callable stand-in for third-party names that are only touched at import time."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+
+def _install_pkg_stubs():
+    install_stubs()
+    if "gdown" not in sys.modules:
+        _stub("gdown", download=None)
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "transforms"):
+        tr = _stub("torchvision.transforms", Compose=_Inert, ToTensor=_Inert, Normalize=_Inert)
+        tv.transforms = tr
+    if "albumentations" not in sys.modules:
+        _stub("albumentations", ImageOnlyTransform=_Inert, Compose=_Inert, Normalize=_Inert)
+        _stub("albumentations.pytorch", ToTensorV2=_Inert)
+    if "tqdm" not in sys.modules:  # present in this image; kept for completeness
+        _stub("tqdm", tqdm=lambda x, **k: x)
+
+
+def _load_into(pkgname, modname, relpath):
+    full = f"{pkgname}.{modname}"
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, REF / relpath)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = pkgname
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    setattr(sys.modules[pkgname], modname, mod)
+    return mod
+
+
+def ref_east_infer():
+    """detectors/_east/infer.py (class EAST: the box tail :134-233 is plain NumPy).  dataset.py and
+    train_utils.py (training, need skimage / tensorboard / torch_optimizer) are stubs."""
+    _install_pkg_stubs()
+    _pkg("refman", None)
+    _pkg("refman.detectors", None)
+    east = _pkg("refman.detectors._east", None)
+    _load_into("refman.detectors", "_types", "detectors/_types.py")
+    _stub("refman.detectors._east.dataset", EASTDataset=None)
+    _stub("refman.detectors._east.train_utils", _run_training=None)
+    for f in ("lanms", "utils", "east"):
+        _load_into("refman.detectors._east", f, f"detectors/_east/{f}.py")
+    mod = _load_into("refman.detectors._east", "infer", "detectors/_east/infer.py")
+    east.EAST = mod.EAST
+    return mod
+
+
+def ref_pipeline():
+    """_pipeline.py with the REAL utils.py functions behind `.detectors`; the default plugin classes
+    (EAST, TRBA — only touched by Pipeline() without arguments) are None."""
+    infer = ref_east_infer()
+    utils = sys.modules["refman.detectors._east.utils"]
+    det = sys.modules["refman.detectors"]
+    det.EAST = infer.EAST
+    for n in ("visualize_page", "read_image", "sort_boxes_reading_order", "sort_boxes_reading_order_with_resolutions"):
+        setattr(det, n, getattr(utils, n))
+    _stub("refman.recognizers", TRBA=None)
+    return _load_into("refman", "_pipeline", "_pipeline.py")
+
+
+def ref_trba_wrapper():
+    """recognizers/_trba/__init__.py (class TRBA).  training/train.py is a stub (Config / run_training = None);
+    data/transforms.py loads behind inert albumentations / cv2 stubs (load_charset and decode_tokens are pure Python)."""
+    _install_pkg_stubs()
+    base = "refman_trba"  # its own root: `refman.recognizers` stays ref_pipeline's stub
+    _pkg(base, "recognizers/_trba")
+    for sub in ("model", "data", "training"):
+        _pkg(f"{base}.{sub}", None)
+    _load_into(f"{base}.model", "seresnet31", "recognizers/_trba/model/seresnet31.py")
+    _load_into(f"{base}.model", "model", "recognizers/_trba/model/model.py")
+    _load_into(f"{base}.data", "transforms", "recognizers/_trba/data/transforms.py")
+    _load_into(f"{base}.training", "utils", "recognizers/_trba/training/utils.py")
+    _stub(f"{base}.training.train", Config=None, run_training=None)
+    spec = importlib.util.spec_from_file_location(base + ".__ref_init__", REF / "recognizers/_trba/__init__.py")
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = base
+    sys.modules[base + ".__ref_init__"] = mod
+    spec.loader.exec_module(mod)
+    return mod
