@@ -38,7 +38,8 @@ struct HuffTable {
   uint16_t look[512];
   int32_t maxcode[18];  // largest code of each length (-1 none), [17] = sentinel
   int32_t valoff[17];
-  void build() {
+  // false: the code lengths do not form a prefix code (libjpeg jdhuff.c jpeg_make_d_derived_tbl -> JERR_BAD_HUFF_TABLE)
+  bool build() {
     int code = 0, k = 0;
     int32_t huffcode[256];
     uint8_t huffsize[256];
@@ -49,6 +50,7 @@ struct HuffTable {
     int si = n ? huffsize[0] : 0;
     while (k < n) {
       while (k < n && huffsize[k] == si) huffcode[k++] = code++;
+      if (code > (1 << si)) return false;  // over-subscribed at this length: more codes than si bits can hold
       code <<= 1;
       ++si;
     }
@@ -69,8 +71,10 @@ struct HuffTable {
     for (int l = 1; l <= 9; ++l)
       for (int i = 0; i < bits[l]; ++i, ++p) {
         const int base = huffcode[p] << (9 - l);
+        if (base + (1 << (9 - l)) > 512) return false;  // unreachable after the check above; keeps the table write in bounds
         for (int c = 0; c < (1 << (9 - l)); ++c) look[base + c] = (uint16_t)((l << 8) | vals[p]);
       }
+    return true;
   }
 };
 
@@ -129,6 +133,36 @@ struct Parsed {
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
+// Largest frame taken (pixels): PIL refuses anything above 2 x MAX_IMAGE_PIXELS (DecompressionBombError), so the host
+// decoder the caller falls back to gives the same answer; below it the coefficient array is at most 0.54 GB.
+constexpr int64_t kMaxPixels = 2 * (int64_t)89478485;
+
+// Exif Orientation (tag 0x0112 of IFD0) of an APP1 payload, 1 when absent / unreadable.
+int exif_orientation(const uint8_t* s, int n) {
+  if (n < 14 || memcmp(s, "Exif\0\0", 6) != 0) return 1;
+  const uint8_t* t = s + 6;
+  const int tn = n - 6;
+  bool le;
+  if (t[0] == 'I' && t[1] == 'I') le = true;
+  else if (t[0] == 'M' && t[1] == 'M') le = false;
+  else return 1;
+  auto u16 = [&](int o) { return le ? (t[o] | (t[o + 1] << 8)) : ((t[o] << 8) | t[o + 1]); };
+  auto u32 = [&](int o) {
+    return le ? ((uint32_t)t[o] | ((uint32_t)t[o + 1] << 8) | ((uint32_t)t[o + 2] << 16) | ((uint32_t)t[o + 3] << 24))
+              : (((uint32_t)t[o] << 24) | ((uint32_t)t[o + 1] << 16) | ((uint32_t)t[o + 2] << 8) | (uint32_t)t[o + 3]);
+  };
+  if (u16(2) != 42) return 1;
+  const uint32_t ifd = u32(4);
+  if (ifd > (uint32_t)tn || (int64_t)ifd + 2 > tn) return 1;
+  const int cnt = u16((int)ifd);
+  for (int e = 0; e < cnt; ++e) {
+    const int64_t o = (int64_t)ifd + 2 + 12 * (int64_t)e;
+    if (o + 12 > tn) return 1;
+    if (u16((int)o) == 0x0112) return (u16((int)o + 2) == 3 && u32((int)o + 4) == 1) ? u16((int)o + 8) : 1;
+  }
+  return 1;
+}
+
 // Walks the markers up to the first SOS.  Returns MSOCR_OK, or MSOCR_E_ARG for a corrupt / unsupported stream.
 int parse(const uint8_t* d, int64_t len, Parsed* P) {
   memset(&P->info, 0, sizeof(P->info));
@@ -178,7 +212,7 @@ int parse(const uint8_t* d, int64_t len, Parsed* P) {
         memcpy(t.vals, s + o, cnt);
         o += cnt;
         t.present = true;
-        t.build();
+        if (!t.build()) return MSOCR_E_ARG;
       }
     } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: baseline / extended sequential, Huffman
       if (n < 6 || have_sof) return MSOCR_E_ARG;
@@ -188,6 +222,7 @@ int parse(const uint8_t* d, int64_t len, Parsed* P) {
       P->info.ncomp = s[5];
       if (P->info.height <= 0 || P->info.width <= 0 || (P->info.ncomp != 1 && P->info.ncomp != 3) || n < 6 + 3 * P->info.ncomp)
         return MSOCR_E_ARG;
+      if ((int64_t)P->info.height * P->info.width > kMaxPixels) return MSOCR_E_ARG;
       for (int c = 0; c < P->info.ncomp; ++c) {
         comp_id[c] = s[6 + 3 * c];
         P->info.hs[c] = s[7 + 3 * c] >> 4;
@@ -201,6 +236,11 @@ int parse(const uint8_t* d, int64_t len, Parsed* P) {
     } else if (m == 0xDD) {
       if (n < 2) return MSOCR_E_ARG;
       P->restart_interval = rd16(s);
+    } else if (m == 0xE1) {
+      // cv2.imread (the reference's read_image) applies the Exif orientation; the device path does not rotate: such files
+      // go to the host decoder, which does (detectors/_east/utils.py read_image)
+      const int orient = exif_orientation(s, n);
+      if (orient >= 2 && orient <= 8) return MSOCR_E_ARG;
     } else if (m == 0xEE && n >= 12 && memcmp(s, "Adobe", 5) == 0) {
       adobe = true;
       adobe_transform = s[11];
@@ -279,7 +319,7 @@ int entropy_decode(const Parsed& P, const uint8_t* end, int16_t* coef) {
             int16_t* blk = coef + f.coef_off[c] + ((int64_t)(my * f.vs[c] + by) * f.blocks_w[c] + (mx * f.hs[c] + bx)) * 64;
             int s = huff_decode(br, dct);
             if (s < 0 || s > 15) return MSOCR_E_ARG;
-            if (s) pred[c] += extend(br.get(s), s);
+            if (s) pred[c] = (int)((uint32_t)pred[c] + (uint32_t)extend(br.get(s), s));  // modulo 2^32: a hostile stream wraps
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
               const int rs = huff_decode(br, act);
@@ -317,27 +357,30 @@ int entropy_decode(const Parsed& P, const uint8_t* end, int16_t* coef) {
 #define C_2_562915447 20995
 #define C_3_072711026 25172
 
-HD int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// All IDCT arithmetic is done modulo 2^32 on unsigned words (identical to libjpeg's signed arithmetic wherever that does not
+// overflow, i.e. for every stream an encoder can produce; a hostile stream wraps instead of being undefined behaviour).
+typedef uint32_t U32;
+HD int descale(U32 x, int n) { return (int32_t)(x + (1u << (n - 1))) >> n; }
 HD uint8_t idct_range_limit(int v) {  // sample_range_limit + CENTERJSAMPLE, indexed with (v & RANGE_MASK)
   const int x = v & 1023;
   return (uint8_t)(x < 128 ? x + 128 : (x < 512 ? 255 : (x < 896 ? 0 : x - 896)));
 }
 
-HD void idct_1d(int d0, int d1, int d2, int d3, int d4, int d5, int d6, int d7, int shift0, int o[8]) {
+HD void idct_1d(U32 d0, U32 d1, U32 d2, U32 d3, U32 d4, U32 d5, U32 d6, U32 d7, int shift0, int o[8]) {
   // even part; d0/d4 are shifted up by CONST_BITS by the caller's convention: tmp0 = (d0 + d4) << CONST_BITS
-  int z1 = (d2 + d6) * C_0_541196100;
-  const int t2 = z1 + d6 * (-C_1_847759065);
-  const int t3 = z1 + d2 * C_0_765366865;
-  const int t0 = (d0 + d4) * (1 << 13);
-  const int t1 = (d0 - d4) * (1 << 13);
-  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  U32 z1 = (d2 + d6) * (U32)C_0_541196100;
+  const U32 t2 = z1 + d6 * (U32)(-C_1_847759065);
+  const U32 t3 = z1 + d2 * (U32)C_0_765366865;
+  const U32 t0 = (d0 + d4) << 13;
+  const U32 t1 = (d0 - d4) << 13;
+  const U32 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
   // odd part
-  int a0 = d7, a1 = d5, a2 = d3, a3 = d1;
+  U32 a0 = d7, a1 = d5, a2 = d3, a3 = d1;
   z1 = a0 + a3;
-  int z2 = a1 + a2, z3 = a0 + a2, z4 = a1 + a3;
-  const int z5 = (z3 + z4) * C_1_175875602;
-  a0 *= C_0_298631336; a1 *= C_2_053119869; a2 *= C_3_072711026; a3 *= C_1_501321110;
-  z1 *= -C_0_899976223; z2 *= -C_2_562915447; z3 *= -C_1_961570560; z4 *= -C_0_390180644;
+  U32 z2 = a1 + a2, z3 = a0 + a2, z4 = a1 + a3;
+  const U32 z5 = (z3 + z4) * (U32)C_1_175875602;
+  a0 *= (U32)C_0_298631336; a1 *= (U32)C_2_053119869; a2 *= (U32)C_3_072711026; a3 *= (U32)C_1_501321110;
+  z1 *= (U32)(-C_0_899976223); z2 *= (U32)(-C_2_562915447); z3 *= (U32)(-C_1_961570560); z4 *= (U32)(-C_0_390180644);
   z3 += z5; z4 += z5;
   a0 += z1 + z3; a1 += z2 + z4; a2 += z2 + z3; a3 += z1 + z4;
   o[0] = descale(t10 + a3, shift0); o[7] = descale(t10 - a3, shift0);
@@ -349,16 +392,16 @@ HD void idct_1d(int d0, int d1, int d2, int d3, int d4, int d5, int d6, int d7, 
 // one 8x8 block: coefficients (natural order) x quantisation table -> 64 samples, row-major with `ld` bytes between rows
 HD void idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, long ld) {
   int ws[64];
+  auto dq = [&](int k) { return (U32)(int32_t)coef[k] * (U32)q[k]; };
   for (int c = 0; c < 8; ++c) {  // pass 1: columns (the all-AC-zero shortcut of the reference gives the same values)
     int o[8];
-    idct_1d(coef[c] * q[c], coef[8 + c] * q[8 + c], coef[16 + c] * q[16 + c], coef[24 + c] * q[24 + c], coef[32 + c] * q[32 + c],
-            coef[40 + c] * q[40 + c], coef[48 + c] * q[48 + c], coef[56 + c] * q[56 + c], 13 - 2, o);
+    idct_1d(dq(c), dq(8 + c), dq(16 + c), dq(24 + c), dq(32 + c), dq(40 + c), dq(48 + c), dq(56 + c), 13 - 2, o);
     for (int r = 0; r < 8; ++r) ws[r * 8 + c] = o[r];
   }
   for (int r = 0; r < 8; ++r) {  // pass 2: rows
     int o[8];
     const int* w = ws + r * 8;
-    idct_1d(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], 13 + 2 + 3, o);
+    idct_1d((U32)w[0], (U32)w[1], (U32)w[2], (U32)w[3], (U32)w[4], (U32)w[5], (U32)w[6], (U32)w[7], 13 + 2 + 3, o);
     for (int c = 0; c < 8; ++c) out[r * ld + c] = idct_range_limit(o[c]);
   }
 }

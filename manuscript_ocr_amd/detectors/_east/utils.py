@@ -12,14 +12,16 @@ fallback branch.
 from pathlib import Path
 
 import numpy as np
-from PIL import Image, ImageDraw
+from PIL import Image, ImageDraw, ImageOps
 
 
 def read_image(img_or_path):
     if isinstance(img_or_path, (str, Path)):
         try:
             with Image.open(str(img_or_path)) as pil_img:
-                return np.array(pil_img.convert("RGB"))
+                # cv2.imread (the reference's first branch, utils.py:480) applies the Exif orientation of the file;
+                # parity unpinned (cv2 absent): restated with PIL's transpose of the same eight cases
+                return np.array(ImageOps.exif_transpose(pil_img).convert("RGB"))
         except Exception as e:  # missing or undecodable file
             raise FileNotFoundError(f"Cannot read image with cv2 or PIL: {img_or_path}. Error: {e}")
     if isinstance(img_or_path, np.ndarray):

@@ -82,3 +82,111 @@ def test_jpeg_restart_intervals_every_subsampling_and_awkward_sizes():
                     continue
                 got = ingest.decode_jpeg_host(data)
                 assert got is not None and np.array_equal(got, _pil_decode(data)), (h, w, sub, kw)
+
+
+def _replace_dht_counts(data, table_index, counts):
+    """Rewrite the 16 code-length counts of the `table_index`-th Huffman table of a stream (symbols untouched)."""
+    out, i, seen = bytearray(data), 2, 0
+    while i + 4 < len(out):
+        assert out[i] == 0xFF
+        m, L = out[i + 1], (out[i + 2] << 8) | out[i + 3]
+        if m == 0xC4:
+            o = i + 4
+            while o < i + 2 + L:
+                n = sum(out[o + 1:o + 17])
+                if seen == table_index:
+                    out[o + 1:o + 17] = bytes(counts)
+                    return bytes(out)
+                seen += 1
+                o += 17 + n
+        if m == 0xDA:
+            break
+        i += 2 + L
+    raise AssertionError("table not found")
+
+
+def test_jpeg_hostile_huffman_tables_are_rejected():
+    """code-length counts that are not a prefix code must be refused as libjpeg refuses them
+    (JERR_BAD_HUFF_TABLE) instead of indexing the 9-bit look-ahead table out of bounds."""
+    data = _encode(_test_images()["smooth"], quality=80)
+    assert ingest.decode_jpeg_host(data) is not None
+    for tbl in range(4):
+        for counts in ([255] + [0] * 15,          # 255 codes of one bit: segfaulted the round-2 parser
+                       [12] + [0] * 15,           # 12 codes of one bit: silently corrupted its tables
+                       [0, 5] + [0] * 14,         # 5 codes of two bits
+                       [1, 1, 1, 1, 1, 1, 1, 1, 3] + [0] * 7):   # over-subscribed only at length 9
+            bad = _replace_dht_counts(data, tbl, counts)
+            assert ingest.jpeg_coefficients(bad) is None, (tbl, counts)
+            with pytest.raises(Exception):
+                _pil_decode(bad)                  # libjpeg's verdict on the same stream
+
+
+def test_jpeg_frame_size_is_capped():
+    """a tiny file must not be able to ask for a 65535 x 65535 frame (13 GB of coefficients)."""
+    data = bytearray(_encode(_test_images()["smooth"], quality=80))
+    i = data.index(b"\xff\xc0")
+    data[i + 5:i + 9] = b"\xff\xff\xff\xff"       # height, width = 65535
+    info, _ = ingest._parse(bytes(data))
+    assert info is None
+    data[i + 5:i + 9] = (13000).to_bytes(2, "big") + (13000).to_bytes(2, "big")   # 169 MP: below PIL's bomb limit, accepted
+    info, _ = ingest._parse(bytes(data))
+    assert info is not None and info.coef_total * 2 < (1 << 30)
+
+
+def test_jpeg_exif_orientation_goes_to_the_host_reader(tmp_path):
+    """cv2.imread (reference read_image, detectors/_east/utils.py:480) applies the Exif orientation: the device decoder
+    reports such files as unsupported and the host reader transposes them (parity unpinned: cv2 absent)."""
+    from manuscript_ocr_amd.detectors import read_image
+    arr = _test_images()["page"]
+    for orient in (1, 3, 6, 8):
+        ex = Image.Exif()
+        ex[0x0112] = orient
+        p = tmp_path / f"o{orient}.jpg"
+        Image.fromarray(arr).save(p, format="JPEG", quality=90, exif=ex.tobytes())
+        data = p.read_bytes()
+        plain = _pil_decode(data)
+        got = ingest.decode_jpeg_host(data)
+        if orient == 1:
+            assert got is not None and np.array_equal(got, plain)
+            assert np.array_equal(read_image(str(p)), plain)
+        else:
+            assert got is None
+            exp = {3: np.rot90(plain, 2), 6: np.rot90(plain, -1), 8: np.rot90(plain, 1)}[orient]
+            assert np.array_equal(read_image(str(p)), exp)
+
+
+def test_jpeg_host_parser_under_sanitizers(tmp_path):
+    """Mutation fuzz of the host parser / entropy decoder / host reconstruction with AddressSanitizer + UBSan on the CPU build
+    of csrc/jpeg.hip (tests/native/jpeg_fuzz.cpp): hostile DHT counts, truncations, header and body byte flips, rewritten
+    segment lengths, stray markers.  GPU sanitizers are not available on the pool; the host half is where files are parsed."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "manuscript_ocr_amd", "csrc", "jpeg.hip")
+    inc = os.path.join(root, "include")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    obj, drv, exe = tmp_path / "jpeg_asan.o", tmp_path / "fuzz.o", tmp_path / "jpeg_fuzz"
+    host_san = [f for s in san for f in ("-Xarch_host", s)]
+    subprocess.check_call([hipcc, "-O1", "-g", *host_san, "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I", inc,
+                           "-c", src, "-o", str(obj)])
+    subprocess.check_call([hipcc, "-O1", "-g", *host_san, "-std=c++17", "--offload-arch=gfx950", "-I", inc, "-x", "hip",
+                           "-c", os.path.join(root, "tests", "native", "jpeg_fuzz.cpp"), "-o", str(drv)])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", san[0], str(obj), str(drv), "-o", str(exe)])
+    arr = _test_images()["page"][:96, :128]
+    seeds = []
+    for k, (q, sub, kw) in enumerate(((80, 2, {}), (90, 0, {"optimize": True}), (60, 1, {"restart_marker_blocks": 2}))):
+        try:
+            data = _encode(arr, quality=q, subsampling=sub, **kw)
+        except TypeError:
+            data = _encode(arr, quality=q, subsampling=sub)
+        (tmp_path / f"s{k}.jpg").write_bytes(data)
+        seeds.append(str(tmp_path / f"s{k}.jpg"))
+    r = subprocess.run([str(exe), "800", *seeds], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "streams" in r.stdout
+    shutil.rmtree(tmp_path, ignore_errors=True)
