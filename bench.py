@@ -645,8 +645,13 @@ def cpu_baseline_random_weight_leg(crops, itos):
     net.load_state_dict(sd)
     net.eval()
     x = torch.from_numpy(((canv.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
-    exp = decode_check.oracle_decode_chunks(net, x, "beam")
-    rep = decode_check.compare_decodes(ids, trun, lg, exp, "beam", logit_rtol=3e-2)
+    keep = []
+    exp = decode_check.oracle_decode_chunks(net, x, "beam", keep_batch_H=keep)
+    # the logit bound is calibrated, as in tests/test_gpu_trba.py: the oracle decoder's own response to an encoder-output
+    # perturbation of the size measured between the device's batch_H and the oracle's
+    cal = decode_check.calibrated_logit_bounds(net, np.concatenate(keep), rec.model.encode(torch.from_numpy(canv).cuda())[0].cpu().numpy(),
+                                               exp, "beam")
+    rep = decode_check.compare_decodes(ids, trun, lg, exp, "beam", logit_rtol=cal["max"])
     got_t = rec.texts(ids, trun)
     exp_t = [otm.decode_tokens(e["ids"], itos, 0, 2, None) for e in exp]
     edits = sum(_lev(a, b) for a, b in zip(exp_t, got_t))
@@ -656,7 +661,10 @@ def cpu_baseline_random_weight_leg(crops, itos):
             "rows_differing_not_at_a_tie": len(rep["hard"]),
             "near_tie_margins": [round(float(t[3]), 6) for t in rep["ties"] if t[3] is not None],
             "tie_tol": decode_check.TIE_TOL, "cer_gpu_vs_cpu": edits / max(1, sum(max(len(t), 1) for t in exp_t)),
-            "logit_err_rel_p90": float(np.quantile(rep["row_logit_err_rel"], 0.9)), "logit_err_rel_max": rep["max_logit_err_rel"]}
+            "logit_err_rel_p90": float(np.quantile(rep["row_logit_err_rel"], 0.9)), "logit_err_rel_max": rep["max_logit_err_rel"],
+            "encoder_err_rel": cal["enc_err_rel"],
+            "calibrated_bound": {"p90": cal["p90"], "max": cal["max"],
+                                 "note": "2x the CPU decoder's own response to an encoder-output perturbation of the measured size"}}
 
 
 def cpu_baseline_real_network_leg(esd, oracle_net, page, hw=(256, 384)):

@@ -89,6 +89,26 @@ int msocr_winograd42_gemm(const msocr_conv_desc* d, const float* u_weight, void*
 int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
                                       void* out, void* stream);
 
+/* ---- split-operand f32 ("bf16x3"): the default arithmetic of the f32 1x1 convolutions and Winograd-domain GEMMs --------------
+ * gfx950 runs exact-f32 MFMA at 1/16 of the bf16 rate.  An f32 value is the exact sum of three bf16 values (round-to-nearest
+ * residual chain); of the nine cross products of two such sums the six largest are accumulated in f32 on the bf16 matrix pipes,
+ * the three dropped ones are <= 2^-25 of the product (below the rounding of the f32 accumulation itself).  The activation operand
+ * is split in registers inside the kernel; the WEIGHT operand is split once at load time:
+ *   msocr_split_bf16x3_host(w, n, planes)   HOST: w [n] f32 -> planes [3][n] bf16 (uint16), w == p0 + p1 + p2 exactly.
+ * msocr_conv1x1_split: msocr_conv2d for KH = KW = 1 / stride 1 / no padding / MSOCR_F32 over a dense pixel sequence
+ *   (in_sH == W * in_sW, in_sN == H * in_sH), Cin % 32 == 0, Cout % 64 == 0; weight_planes = [3][Cout][Cin] bf16 on the device.
+ *   Same flags, epilogue and reference layers as msocr_conv2d (torchvision Bottleneck conv1 / conv3 / downsample, DecoderBlock
+ *   conv1x1, SEBasicBlock downsample, the BiLSTM input projections and linears).
+ * msocr_winograd42_gemm_split / msocr_conv3x3_winograd42_split: stage 2 of / the whole msocr_conv3x3_winograd42 with
+ *   u_planes = [3][24][Cout][Cin] bf16 = msocr_split_bf16x3_host of msocr_winograd42_weights_host's output (Cin % 32, Cout % 64).
+ * Results differ from the exact-f32 entry points by rounding only (tests/test_gpu_ops.py bounds both against an f64 reference). */
+int msocr_split_bf16x3_host(const float* w_host, int64_t n, uint16_t* planes_out_host);
+int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
+                        const void* residual, void* out, void* stream);
+int msocr_winograd42_gemm_split(const msocr_conv_desc* d, const void* u_planes, void* workspace, void* stream);
+int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                   const void* residual, void* out, void* workspace, void* stream);
+
 /* Cin == 64: the tall Winograd form with the 24 transform-domain GEMMs (K = 64) and the output transform fused in one kernel, so
  * Mw never reaches HBM (unfused, a 64-channel layer is HBM-bound on Mw).  workspace holds V only
  * (msocr_conv3x3_winograd42_fused_workspace_bytes; -1 = unsupported: Cin != 64, Cout % 32, or POOL2 with odd H / W or a residual).

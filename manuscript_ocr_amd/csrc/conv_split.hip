@@ -1,0 +1,314 @@
+// conv_split.hip — f32 GEMM / 1x1 convolution on the bf16 matrix pipes with EXACTLY split operands ("bf16x3").
+//
+// gfx950 runs exact-f32 MFMA (v_mfma_f32_32x32x2_f32) at 1/16 of the bf16 rate.  An f32 value splits exactly into three bf16
+// terms, a = a0 + a1 + a2 (round-to-nearest residuals: |a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|), so
+//     a * b = a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0) + [a1b2 + a2b1 + a2b2],
+// and the bracket is <= 2^-25 |ab|: below the rounding of the f32 accumulation both paths share.  The six kept products run on
+// v_mfma_f32_32x32x16_bf16 (products of bf16 values are exact in f32; f32 accumulate), smallest terms first: 6 bf16 MFMAs
+// replace 8 f32 MFMAs of 1/16 the rate each — the K loop costs 6 x 32 cycles per 32x32x16 block instead of 8 x 64.
+//
+// Operands: A = activations (or the Winograd-domain V) as plain f32 in HBM, split IN REGISTERS on the way into LDS (three
+// v_cvt_pk_bf16_f32 + two subtractions per pair); B = weights (or the Winograd U), split ONCE at load time into three bf16
+// planes [3][Cout][K] (msocr_split_bf16x3_host / ops.py).  Same tile as conv_igemm.hip's lean kernel: 128 x 128 (or 128 x 64) per
+// workgroup, 4 waves of 64 x 64 (64 x 32), K-tiles of 32, one LDS stage of six [rows][64 B] planes (16-B chunks XOR-swizzled by
+// row), 3 workgroups per CU; the epilogue (bias, residual, ReLU, 16-byte stores) is the exact-f32 kernel's.
+//
+// Used for every launch the lean exact-f32 GEMM served (1x1 / stride 1 / no padding convolutions, the LSTM / linear GEMMs and
+// the batched Winograd-domain GEMMs) unless the caller asks for precision = "fp32-exact".  Reference layers:
+//   recognizers/_trba/model/seresnet31.py:37-67 ; detectors/_east/east.py:13-30 ; torchvision Bottleneck conv1 / conv3
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "conv_common.h"
+#include "internal.h"
+#include "msocr.h"
+
+namespace {
+
+// two f32 -> (packed bf16 pair of the leading terms, the two residuals)
+__device__ __forceinline__ uint32_t split_step(float& x, float& y) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x, y};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+  const uint32_t pk = __builtin_bit_cast(uint32_t, h);
+  x -= __uint_as_float(pk << 16);          // exact: the leading term shares x's exponent
+  y -= __uint_as_float(pk & 0xffff0000u);
+  return pk;
+}
+
+// BN in {128, 64}; wave tile 64 x WN (WN = BN / 2); K-tile = 32 elements (A rows 128 B of f32 in HBM, 64 B per bf16 plane in LDS)
+template <int BN, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
+  constexpr int BM = 128, WM = 64, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int ROWB = 64;                 // bytes per LDS plane row (32 bf16)
+  constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
+  constexpr int A_IT = BM / 32;            // A: 8 x 16-B chunks per f32 row, 32 rows per pass of 256 threads
+  constexpr int B_IT = BN / 64;            // B: 4 x 16-B chunks per bf16 row, 64 rows per pass; per plane
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sA = smem;                 // [3][BM][64 B]
+  unsigned char* const sB = smem + 3 * A_PLANE;   // [3][BN][64 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile mapping (as conv_igemm_kernel): each XCD gets a contiguous range of logical tiles
+  const int nblk1 = p.tilesM * p.tilesN;
+  const int nblk = nblk1 * p.nbatch;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int batch = bid / nblk1;
+  bid -= batch * nblk1;
+  const int tile_n = bid % p.tilesN;
+  const int tile_m = bid / p.tilesN;
+  const char* const g_in = p.in + (long)batch * p.bsA * 4;
+  const char* const g_w = p.w + (long)batch * p.bsW * 2;
+  char* const g_out = p.out + (long)batch * p.bsO * 4;
+
+  // ---- staging coordinates ----
+  const int a_chunk = tid & 7, a_row0 = tid >> 3;
+  const char* a_ptr[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    long m = (long)tile_m * BM + a_row0 + i * 32;
+    if (m >= p.M) m = p.M - 1;  // rows past the end: valid addresses, values never stored
+    // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements)
+    a_ptr[i] = g_in + (m * p.sW + a_chunk * 4) * 4;
+  }
+  const int b_chunk = tid & 3, b_row0 = tid >> 2;
+  const char* b_ptr[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int co = tile_n * BN + b_row0 + j * 64;
+    b_ptr[j] = g_w + ((long)co * p.Ktot + b_chunk * 8) * 2;
+  }
+  const long wplane_b = p.wplane * 2;
+
+  u32x4 ra[A_IT], rb[3][B_IT];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (long)kt * 128);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < B_IT; ++j) rb[pl][j] = *reinterpret_cast<const u32x4*>(b_ptr[j] + pl * wplane_b + (long)kt * 64);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = a_row0 + i * 32;
+      float x0 = __uint_as_float(ra[i][0]), x1 = __uint_as_float(ra[i][1]), x2 = __uint_as_float(ra[i][2]), x3 = __uint_as_float(ra[i][3]);
+      // this thread's 4 elements are bf16 positions 4 * a_chunk .. + 3 of the row: half of 16-B chunk a_chunk / 2
+      unsigned char* dst = sA + row * ROWB + (((a_chunk >> 1) ^ swz<ROWB>(row)) << 4) + ((a_chunk & 1) << 3);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x2 v;
+        v[0] = split_step(x0, x1);
+        v[1] = split_step(x2, x3);
+        *reinterpret_cast<u32x2*>(dst + pl * A_PLANE) = v;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < B_IT; ++j) {
+        const int row = b_row0 + j * 64;
+        *reinterpret_cast<u32x4*>(sB + pl * B_PLANE + row * ROWB + ((b_chunk ^ swz<ROWB>(row)) << 4)) = rb[pl][j];
+      }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int r32 = lane & 31, half = lane >> 5;
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  for (int kt = 0; kt < p.ktiles; ++kt) {
+    if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {              // two k16 steps per K-tile
+      const int c = 2 * q + half;
+      bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * WM + i * 32 + r32;
+          fa[pl][i] = *reinterpret_cast<const bf16x8*>(sA + pl * A_PLANE + row * ROWB + ((c ^ swz<ROWB>(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * WN + j * 32 + r32;
+          fb[pl][j] = *reinterpret_cast<const bf16x8*>(sB + pl * B_PLANE + row * ROWB + ((c ^ swz<ROWB>(row)) << 4));
+        }
+      }
+      // smallest terms first; consecutive MFMAs of one product class hit different accumulators
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // one LDS stage: everyone is done reading before it is overwritten
+    if (kt + 1 < p.ktiles) store_tile();
+    __syncthreads();
+  }
+
+  // ---- epilogue (conv_igemm_kernel's): TM passes of (acc row-block -> LDS [64][BN] f32 -> bias/residual/ReLU -> 16-B stores) ----
+  constexpr int PR = (BM / WM) * 32;
+  float* sc = reinterpret_cast<float*>(smem);
+  constexpr int VPR = BN / 4;
+  constexpr int ROWS_PP = 256 / VPR;
+  const int vcol = (tid % VPR) * 4;
+  const int vrow0 = tid / VPR;
+  const int co = tile_n * BN + vcol;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rit = (e & 3) + 8 * (e >> 2) + 4 * half;
+        sc[(wm * 32 + rit) * BN + wn * WN + j * 32 + r32] = acc[i][j][e];
+      }
+    __syncthreads();
+    for (int lr = vrow0; lr < PR; lr += ROWS_PP) {
+      const int trow = (lr >> 5) * WM + i * 32 + (lr & 31);
+      const long m = (long)tile_m * BM + trow;
+      if (m >= p.M) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sc[lr * BN + vcol]) + bias;
+      if (p.has_res) v += *reinterpret_cast<const f32x4*>(p.res + (m * p.res_ld + co) * 4);
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *reinterpret_cast<f32x4*>(g_out + (m * p.out_ld + co) * 4) = v;
+    }
+  }
+}
+
+template <int BN, int WPE>
+int launch_split(ConvParams& p, hipStream_t s) {
+  p.tilesM = (int)((p.M + 127) / 128);
+  p.tilesN = p.Cout / BN;
+  p.ktiles = (int)(p.Ktot / 32);
+  constexpr int STAGE = 3 * (128 + BN) * 64;
+  constexpr int EPI = 64 * BN * 4;
+  constexpr int LDS = STAGE > EPI ? STAGE : EPI;
+  auto kern = conv_split_kernel<BN, WPE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr_set = true;
+  }
+  const long nblk = (long)p.tilesM * p.tilesN * p.nbatch;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), LDS, s, p);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+int launch_split_any(ConvParams& p, hipStream_t s) {
+  static const int wpe = getenv("MSOCR_SPLIT_WPE") ? atoi(getenv("MSOCR_SPLIT_WPE")) : 3;
+  if (p.Cout % 128 == 0) return wpe == 2 ? launch_split<128, 2>(p, s) : launch_split<128, 3>(p, s);
+  return wpe == 2 ? launch_split<64, 2>(p, s) : launch_split<64, 3>(p, s);
+}
+
+}  // namespace
+
+// HOST helper: w [n] f32 -> planes [3][n] bf16 with w == p0 + p1 + p2 exactly (round-to-nearest-even residual chain, the same
+// arithmetic the kernel applies to its activation operand).
+extern "C" int msocr_split_bf16x3_host(const float* w_host, int64_t n, uint16_t* planes_out_host) {
+  if (!w_host || !planes_out_host || n <= 0) return MSOCR_E_ARG;
+  auto rne = [](float f) -> uint16_t {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto up = [](uint16_t h) -> float {
+    return __builtin_bit_cast(float, (uint32_t)h << 16);
+  };
+  for (int64_t i = 0; i < n; ++i) {
+    float r = w_host[i];
+    for (int pl = 0; pl < 3; ++pl) {
+      const uint16_t h = rne(r);
+      planes_out_host[pl * n + i] = h;
+      r -= up(h);
+    }
+  }
+  return MSOCR_OK;
+}
+
+// 1x1 / stride 1 / no padding convolution (a GEMM over pixels) with the weight operand given as three bf16 planes
+// [3][Cout][Cin] (plane stride Cout * Cin).  Same descriptor, epilogue flags and error behaviour as msocr_conv2d.
+extern "C" int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
+                                   const void* residual, void* out, void* stream) {
+  if (!d || !in || !weight_planes || !out) return MSOCR_E_ARG;
+  if (d->dtype != MSOCR_F32 || d->KH != 1 || d->KW != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h || d->pad_w) return MSOCR_E_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho != d->H || d->Wo != d->W) return MSOCR_E_ARG;
+  if (d->Cin <= 0 || d->Cin % 32 || d->Cout <= 0 || d->Cout % 64) return MSOCR_E_ARG;
+  // the pixels must form ONE dense row sequence: pixel stride sW, rows and images contiguous in units of it
+  if (d->in_sW % 4 || d->in_sW < d->Cin || (d->H > 1 && d->in_sH != (int64_t)d->W * d->in_sW) ||
+      (d->N > 1 && d->in_sN != (int64_t)d->H * d->W * d->in_sW)) return MSOCR_E_ARG;
+  if (d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)weight_planes | (uintptr_t)out) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  ConvParams p = {};
+  p.in = (const char*)in; p.w = (const char*)weight_planes; p.bias = bias; p.res = (const char*)residual; p.out = (char*)out;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.sN = d->in_sN; p.sH = d->in_sH; p.sW = d->in_sW;
+  p.KH = p.KW = 1; p.SH = p.SW = 1; p.PH = p.PW = 0;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.M = (long)d->N * d->Ho * d->Wo;
+  p.Ktot = d->Cin;
+  p.out_ld = d->out_ld; p.res_ld = d->res_ld;
+  p.relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
+  p.has_res = has_res ? 1 : 0;
+  p.nbatch = 1; p.bsA = p.bsW = p.bsO = 0;
+  p.wplane = (long)d->Cout * d->Cin;
+  return launch_split_any(p, (hipStream_t)stream);
+}
+
+// nbatch independent GEMMs of one shape in ONE launch, C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]: A f32 [nbatch][M][K],
+// B as three bf16 planes [3][nbatch][N][K], C f32 [nbatch][M][N].  The Winograd-domain GEMMs (winograd.hip).
+int msocr_internal_gemm_split_batched(const float* A, const uint16_t* Bplanes, float* C, long M, int N, int K, int nbatch, hipStream_t s) {
+  if (!A || !Bplanes || !C || M <= 0 || N <= 0 || N % 64 || K <= 0 || K % 32 || nbatch <= 0) return MSOCR_E_ARG;
+  if (((uintptr_t)A | (uintptr_t)Bplanes | (uintptr_t)C) & 15) return MSOCR_E_ARG;
+  if (M > 0x7fffffffL) return MSOCR_E_ARG;
+  ConvParams p = {};
+  p.in = (const char*)A; p.w = (const char*)Bplanes; p.bias = nullptr; p.res = nullptr; p.out = (char*)C;
+  p.N = 1; p.H = (int)M; p.W = 1; p.Cin = K;
+  p.sN = M * (long)K; p.sH = K; p.sW = K;
+  p.KH = p.KW = 1; p.SH = p.SW = 1; p.PH = p.PW = 0;
+  p.Ho = (int)M; p.Wo = 1; p.Cout = N;
+  p.M = M; p.Ktot = K;
+  p.out_ld = N; p.res_ld = 0;
+  p.relu = 0; p.has_res = 0;
+  p.nbatch = nbatch; p.bsA = M * (long)K; p.bsW = (long)N * K; p.bsO = M * (long)N;
+  p.wplane = (long)nbatch * N * K;
+  return launch_split_any(p, s);
+}

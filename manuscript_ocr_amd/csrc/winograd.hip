@@ -342,6 +342,16 @@ extern "C" int msocr_winograd42_gemm(const msocr_conv_desc* d, const float* u_we
   return msocr_internal_gemm_f32_batched(V, u_weight, V + 24 * g.Mt * (long)d->Cin, g.Mt, d->Cout, d->Cin, 24, (hipStream_t)stream);
 }
 
+// The 24 transform-domain GEMMs on the bf16 matrix pipes with exactly split operands (conv_split.hip): V split in registers,
+// U given as three bf16 planes [3][24][Cout][Cin] (msocr_split_bf16x3_host of msocr_winograd42_weights_host's output).
+extern "C" int msocr_winograd42_gemm_split(const msocr_conv_desc* d, const void* u_planes, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino42_check(d, &g) != MSOCR_OK || !u_planes || !workspace || d->Cin % 32 || d->Cout % 64) return MSOCR_E_ARG;
+  float* V = (float*)workspace;
+  return msocr_internal_gemm_split_batched(V, (const uint16_t*)u_planes, V + 24 * g.Mt * (long)d->Cin, g.Mt, d->Cout, d->Cin, 24,
+                                           (hipStream_t)stream);
+}
+
 extern "C" int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias,
                                                  const void* residual, void* out, void* stream) {
   WinoGeom g;
@@ -365,6 +375,16 @@ extern "C" int msocr_conv3x3_winograd42(const msocr_conv_desc* d, const void* in
   int rc = msocr_winograd42_input_transform(d, in, workspace, stream);
   if (rc != MSOCR_OK) return rc;
   rc = msocr_winograd42_gemm(d, u_weight, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  return msocr_winograd42_output_transform(d, workspace, bias, residual, out, stream);
+}
+
+extern "C" int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                              const void* residual, void* out, void* workspace, void* stream) {
+  if (!u_planes) return MSOCR_E_ARG;
+  int rc = msocr_winograd42_input_transform(d, in, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  rc = msocr_winograd42_gemm_split(d, u_planes, workspace, stream);
   if (rc != MSOCR_OK) return rc;
   return msocr_winograd42_output_transform(d, workspace, bias, residual, out, stream);
 }

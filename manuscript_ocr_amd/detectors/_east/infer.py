@@ -7,7 +7,9 @@ network, quad decode and locality-aware NMS run on the MI355X through libmsocr.s
 without a HIP device raises.
 
 Extensions (keyword-only, all optional):
-  precision   "fp32" (parity mode, exact-f32 MFMA) | "bf16" (throughput mode, f32 accumulate)
+  precision   "fp32" (parity mode: f32 tensors and accumulation; the 1x1 / Winograd-domain GEMMs run on the bf16 matrix pipes with
+              each operand split exactly into three bf16 terms) | "fp32-exact" (exact-f32 MFMA everywhere) |
+              "bf16" (throughput mode, f32 accumulate)
   state_dict  in-memory weights in the reference key layout (offline: no download is possible)
   target_size may also be a (W, H) tuple: native non-square network input (multiples of 32)
   predict_batch(pages)  list/array of same-sized RGB pages -> list of result dicts, one launch
@@ -74,8 +76,12 @@ class EAST:
                 raise FileNotFoundError(f"EAST weights not found: {weights_path}")
             state_dict = torch.load(str(weights_path), map_location="cpu", weights_only=True)
         self.precision = precision
-        dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[precision]
-        self.model = EastNet(state_dict, dtype=dtype, device=self.device)
+        if precision not in ("fp32", "fp32-exact", "bf16"):
+            raise ValueError(f"precision must be 'fp32', 'fp32-exact' or 'bf16', got {precision!r}")
+        dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        # "fp32": f32 tensors; 1x1 convolutions and Winograd-domain GEMMs on the bf16 matrix pipes with exactly split operands
+        # (csrc/conv_split.hip); "fp32-exact": exact-f32 MFMA in every layer
+        self.model = EastNet(state_dict, dtype=dtype, device=self.device, split=(False if precision == "fp32-exact" else None))
 
         self.target_size = target_size
         self.score_geo_scale = score_geo_scale

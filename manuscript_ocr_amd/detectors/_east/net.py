@@ -32,9 +32,10 @@ def fold_bn(w, conv_bias, prefix_bn, sd):
     return w2, b2
 
 
-def to_khwc(w, dtype, device):
-    """OIHW -> [Cout][KH][KW][Cin] on the device; 3x3 f32 weights also get their Winograd twin (ops.attach_winograd)."""
-    return ops.attach_winograd(w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device))
+def to_khwc(w, dtype, device, split=None):
+    """OIHW -> [Cout][KH][KW][Cin] on the device; 3x3 f32 weights also get their Winograd twin (ops.attach_winograd), f32 1x1 weights
+    and the tall-Winograd U their three bf16 planes (ops.attach_split; split=False keeps a layer on the exact-f32 MFMA)."""
+    return ops.attach_split(ops.attach_winograd(w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), split), split)
 
 
 def pack_stem_weight(w, cin_pad, cpad=4):
@@ -56,7 +57,8 @@ def stem_view(canvas, cin_pad, kw=None):
 
 
 class EastNet:
-    def __init__(self, state_dict, dtype=torch.float32, device="cuda"):
+    def __init__(self, state_dict, dtype=torch.float32, device="cuda", split=None):
+        """split: None = ops.SPLIT_BF16X3 (default on), False = exact-f32 MFMA for every f32 layer (precision="fp32-exact")."""
         self.dtype, self.device = dtype, torch.device(device)
         sd = {k: v for k, v in state_dict.items()}
         P = {}
@@ -73,16 +75,16 @@ class EastNet:
                 p = f"{bb}{lname}.{i}."
                 for j in (1, 2, 3):
                     w, b = conv_bn(p + f"conv{j}", p + f"bn{j}")
-                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
                 if i == 0:
                     w, b = conv_bn(p + "downsample.0", p + "downsample.1")
-                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
         for k in (1, 2, 3, 4):
             p = f"decoder.block{k}."
             w, b = conv_bn(p + "conv1x1.0", p + "conv1x1.1", p + "conv1x1.0.bias")
-            P[f"dec{k}.a"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+            P[f"dec{k}.a"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
             w, b = conv_bn(p + "conv3x3.0", p + "conv3x3.1", p + "conv3x3.0.bias")
-            P[f"dec{k}.b"] = (to_khwc(w, dtype, self.device), b.to(self.device))
+            P[f"dec{k}.b"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
         w9 = torch.cat([sd["output_head.score_map.weight"].float().view(1, 32), sd["output_head.geo_map.weight"].float().view(8, 32)])
         b9 = torch.cat([sd["output_head.score_map.bias"].float().view(1), sd["output_head.geo_map.bias"].float().view(8)])
         self.w9, self.b9 = w9.contiguous().to(self.device), b9.contiguous().to(self.device)

@@ -115,7 +115,31 @@ def _tall_pays(H):
 WINOGRAD_FUSED64 = int(os.environ.get("MSOCR_WINO_FUSED64", "1"))
 
 
-def attach_winograd(w):
+# Split-operand f32 ("bf16x3", csrc/conv_split.hip): the f32 1x1 convolutions and the Winograd-domain GEMMs of the tall form run on
+# the bf16 matrix pipes with each operand split EXACTLY into three bf16 terms (six products per f32 product, f32 accumulate; the
+# dropped terms are <= 2^-25 of a product).  The weight operand is split once, here, at load time.  0 = exact-f32 MFMA everywhere
+# (precision="fp32-exact" of EAST / TRBA).
+SPLIT_BF16X3 = int(os.environ.get("MSOCR_SPLIT", "1"))
+
+
+def split_planes(t):
+    """f32 tensor (any device) -> bf16 tensor [3, *t.shape] on t's device with t == p0 + p1 + p2 exactly (msocr_split_bf16x3_host)."""
+    th = t.detach().float().cpu().contiguous()
+    planes = torch.empty((3,) + tuple(th.shape), dtype=torch.int16)
+    nat.check(nat.lib().msocr_split_bf16x3_host(th.data_ptr(), th.numel(), planes.data_ptr()), "split_bf16x3_host")
+    return planes.view(torch.bfloat16).to(t.device)
+
+
+def attach_split(w, split=None):
+    """Load-time: give a [Cout,1,1,Cin] f32 device weight its three bf16 planes; conv2d() then takes msocr_conv1x1_split for
+    1x1 / stride 1 / no padding calls on pixel-dense inputs."""
+    Cout, KH, KW, Cin = w.shape
+    if (SPLIT_BF16X3 if split is None else split) and w.dtype == torch.float32 and KH == 1 and KW == 1 and Cin % 32 == 0 and Cout % 64 == 0:
+        w._msocr_split = split_planes(w)
+    return w
+
+
+def attach_winograd(w, split=None):
     """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twins U = G g G^T ([16,Cout,Cin] f32 for F(2x2,3x3),
     [24,Cout,Cin] for the tall form F(4,3) x F(2,3); computed on the host in f64 by msocr_winograd[42]_weights_host).  conv2d() then
     takes the Winograd path for 3x3/1/1 calls."""
@@ -137,6 +161,8 @@ def attach_winograd(w):
     u42 = torch.empty((24, Cout, Cin), dtype=torch.float32)
     nat.check(nat.lib().msocr_winograd42_weights_host(wh.data_ptr(), Cout, Cin, u42.data_ptr()), "winograd42_weights_host")
     w._msocr_wino42 = u42.to(w.device)
+    if (SPLIT_BF16X3 if split is None else split) and Cin % 32 == 0 and Cout % 64 == 0:
+        w._msocr_wino42_split = split_planes(u42).to(w.device)  # [3][24][Cout][Cin] bf16
     return w
 
 
@@ -240,6 +266,9 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
             u = w._msocr_wino42
             name, f_ws, whole = "winograd42", L.msocr_conv3x3_winograd42_workspace_bytes, L.msocr_conv3x3_winograd42
             st_in, st_gemm, st_out = L.msocr_winograd42_input_transform, L.msocr_winograd42_gemm, L.msocr_winograd42_output_transform
+            up = getattr(w, "_msocr_wino42_split", None)
+            if up is not None and SPLIT_BF16X3:  # the 24 GEMMs on the bf16 pipes with exactly split operands
+                u, name, whole, st_gemm = up, "winograd42_split", L.msocr_conv3x3_winograd42_split, L.msocr_winograd42_gemm_split
             TH, TW, npts = (Ho + 3) // 4, (Wo + 1) // 2, 24
         elif rs:
             name, f_ws, whole = "winograd_rs", L.msocr_conv3x3_winograd_rs_workspace_bytes, L.msocr_conv3x3_winograd_rs
@@ -277,10 +306,18 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
                 _prof_end(e, "wino_out", 4.0 * (m_el + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))
         d.N = N
     else:
+        wp = getattr(w, "_msocr_split", None)
+        split = (wp is not None and SPLIT_BF16X3 and (KH, KW, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and (Ho, Wo) == (H, W)
+                 and x.stride(1) == W * x.stride(2) and (N == 1 or x.stride(0) == H * W * x.stride(2)))
         e = _prof_begin()
-        rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
-        nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
-        _prof_end(e, "conv_gemm", (alg, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin), (N * Ho * Wo, Cout, KH * KW * Cin, "direct"))
+        if split:
+            rc = nat.lib().msocr_conv1x1_split(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), bp, rp, out.data_ptr(), _stream())
+            nat.check(rc, f"msocr_conv1x1_split {tuple(x.shape)} * {tuple(w.shape)}")
+        else:
+            rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
+            nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
+        _prof_end(e, "conv_gemm", (alg, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin),
+                  (N * Ho * Wo, Cout, KH * KW * Cin, "direct_split" if split else "direct"))
     return out
 
 

@@ -87,8 +87,10 @@ class TRBA:
             obj = torch.load(self.model_path, map_location="cpu", weights_only=True)
             state_dict = obj["model_state"] if isinstance(obj, dict) and "model_state" in obj else obj  # training/utils.py:54-59
         self.precision = precision
-        self.model = TrbaNet(state_dict, len(self.itos), self.hidden_size,
-                             {"fp32": torch.float32, "bf16": torch.bfloat16}[precision], self.device)
+        if precision not in ("fp32", "fp32-exact", "bf16"):
+            raise ValueError(f"precision must be 'fp32', 'fp32-exact' or 'bf16', got {precision!r}")
+        self.model = TrbaNet(state_dict, len(self.itos), self.hidden_size, torch.bfloat16 if precision == "bf16" else torch.float32,
+                             self.device, split=(False if precision == "fp32-exact" else None))
 
     # ------------------------------------------------------------------------------------- paths
     def _resolve_paths(self, model_path, config_path) -> Tuple[str, Optional[str]]:

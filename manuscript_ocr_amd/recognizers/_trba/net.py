@@ -41,7 +41,7 @@ LAYER_SPEC = (("layer1", 1, 2), ("layer2", 2, 1), ("layer3", 5, 2), ("layer4", 3
 
 
 class TrbaNet:
-    def __init__(self, state_dict, num_classes, hidden=256, dtype=torch.float32, device="cuda"):
+    def __init__(self, state_dict, num_classes, hidden=256, dtype=torch.float32, device="cuda", split=None):
         if hidden != 256:
             raise ValueError("the HIP recurrent/attention kernels are built for hidden_size=256 (the reference default)")
         if num_classes > 256:
@@ -55,22 +55,22 @@ class TrbaNet:
         w, b = _fold(sd, "cnn.conv0.0", "cnn.conv0.1")
         P["stem"] = (pack_stem_weight(w, self.cin_pad, self.cpad).to(dtype).to(dev), b.to(dev))
         w, b = _fold(sd, "cnn.conv0.3", "cnn.conv0.4")
-        P["conv0b"] = (to_khwc(w, dtype, dev), b.to(dev))
+        P["conv0b"] = (to_khwc(w, dtype, dev, split), b.to(dev))
         for lname, blocks, stride in LAYER_SPEC:
             for i in range(blocks):
                 p = f"cnn.{lname}.{i}."
                 for j in (1, 2):
                     w, b = _fold(sd, p + f"conv{j}", p + f"bn{j}")
-                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, dev), b.to(dev))
+                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, dev, split), b.to(dev))
                 P[f"{lname}.{i}.se"] = (sd[p + "se.fc.0.weight"].float().contiguous().to(dev),
                                         sd[p + "se.fc.2.weight"].float().contiguous().to(dev))
                 if p + "downsample.0.weight" in sd:
                     w, b = _fold(sd, p + "downsample.0", p + "downsample.1")
-                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, dev), b.to(dev))
+                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, dev, split), b.to(dev))
         w, b = _fold(sd, "cnn.conv_out.0", "cnn.conv_out.1")
-        P["out0"] = (to_khwc(w, dtype, dev), b.to(dev))
+        P["out0"] = (to_khwc(w, dtype, dev, split), b.to(dev))
         w, b = _fold(sd, "cnn.conv_out.3", "cnn.conv_out.4")
-        P["out1"] = (to_khwc(w, dtype, dev), b.to(dev))
+        P["out1"] = (to_khwc(w, dtype, dev, split), b.to(dev))
         self.P = P
         # ---- BiLSTM x2 (f32) ----
         H = hidden

@@ -12,20 +12,27 @@ Attention._beam_decode top-k (model.py:161-163) and final arg-max (model.py:218)
 TIE_TOL = 5e-3
 
 
-def oracle_decode_chunks(trba_net, x_all, mode, chunk=32, max_len=25):
+def oracle_decode_chunks(trba_net, x_all, mode, chunk=32, max_len=25, batch_H=None, keep_batch_H=None):
     """The reference's TRBA.predict loop (recognizers/_trba/__init__.py:374-412) on the CPU oracle: one model call per
     `chunk` rows.  Returns a list with one dict per row: ids [T_run], logits [T_run, V], and the margins of the decisions the
-    oracle's own decode took for that row (oracle/trba_model.py `diag`)."""
+    oracle's own decode took for that row (oracle/trba_model.py `diag`).
+    `batch_H` (optional, [N, T, H]): decode from THIS encoder output instead of encoding x_all (TRBANet.forward is
+    encode + attn, so with batch_H = the oracle's own chunk-wise encode the result is the same); `keep_batch_H` (a list)
+    receives the oracle's chunk-wise encoder outputs."""
     import numpy as np
     import torch
     rows = []
-    for c0 in range(0, x_all.shape[0], chunk):
+    n = x_all.shape[0] if batch_H is None else batch_H.shape[0]
+    for c0 in range(0, n, chunk):
         d = {}
         with torch.no_grad():
+            enc = trba_net.encode(x_all[c0:c0 + chunk]) if batch_H is None else torch.as_tensor(batch_H[c0:c0 + chunk])
+            if keep_batch_H is not None:
+                keep_batch_H.append(enc.numpy().copy())
             if mode == "greedy":
-                lg, ids = trba_net(x_all[c0:c0 + chunk], max_len=max_len, mode="greedy", diag=d)
+                lg, ids = trba_net.attn.greedy(enc, max_len, d)
             else:
-                lg, ids = trba_net(x_all[c0:c0 + chunk], max_len=max_len, mode="beam", beam_size=8, alpha=0.9, temperature=1.7, diag=d)
+                lg, ids = trba_net.attn.beam(enc, max_len, 8, 0.9, 1.7, d)
         lg, ids = lg.numpy(), ids.numpy()
         for j in range(ids.shape[0]):
             r = {"ids": ids[j], "logits": lg[j], "chunk": c0 // chunk}
@@ -93,3 +100,45 @@ def compare_decodes(got_ids, got_trun, got_logits, exp_rows, mode, tie_tol=TIE_T
             rep["hard"].append((i, -1, "run-length", None))
     rep["run_length_only"] = [i for i, ch in runlen if ch in rep["chunks_with_ties"]]
     return rep
+
+
+def row_logit_errors(rows_a, rows_b):
+    """Per-row max |logit_a - logit_b| / max(1, max|logit_b|) over the steps up to and including the first step where the ids
+    differ — the quantity compare_decodes bounds (rep["row_logit_err_rel"]), here between two ORACLE decodes."""
+    import numpy as np
+    out = []
+    for a, b in zip(rows_a, rows_b):
+        T = min(len(a["ids"]), len(b["ids"]))
+        neq = np.flatnonzero(np.asarray(a["ids"][:T]) != np.asarray(b["ids"][:T]))
+        upto = T if len(neq) == 0 else int(neq[0]) + 1
+        scale = max(1.0, float(np.abs(b["logits"][:upto]).max()))
+        out.append(float(np.abs(a["logits"][:upto] - b["logits"][:upto]).max()) / scale)
+    return np.array(out)
+
+
+def calibrated_logit_bounds(trba_net, ref_batch_H, dev_batch_H, exp_rows, mode, chunk=32, max_len=25, draws=4, seed=0):
+    """Where the device's decoder-logit error may lie, DERIVED instead of chosen: the device's encoder output differs from the
+    oracle's by delta = dev_batch_H - ref_batch_H (measured, f32 rounding of a different summation order).  The oracle's own
+    decoder is re-run on ref_batch_H + Gaussian noise whose per-row RMS equals that row's measured RMS of delta (`draws`
+    independent draws) and on dev_batch_H itself; the per-row logit error of those runs against the unperturbed oracle decode
+    is the decoder's own response to an input error of the device's size.  Returns a dict with the pooled noise-response
+    distribution (`oracle_noise`), the response to the device's actual delta (`oracle_on_dev_H`), the measured relative
+    encoder error, and the bounds a device decode has to meet: p50 / p90 / max <= `factor` x the oracle's own (factor 2)."""
+    import numpy as np
+    ref_batch_H, dev_batch_H = np.asarray(ref_batch_H, dtype=np.float32), np.asarray(dev_batch_H, dtype=np.float32)
+    delta = dev_batch_H - ref_batch_H
+    row_rms = np.sqrt((delta.reshape(len(delta), -1) ** 2).mean(axis=1))
+    rng = np.random.default_rng(seed)
+    pooled = []
+    for _ in range(draws):
+        noise = rng.standard_normal(ref_batch_H.shape).astype(np.float32) * row_rms[:, None, None]
+        pert = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=ref_batch_H + noise)
+        pooled.append(row_logit_errors(pert, exp_rows))
+    pooled = np.concatenate(pooled)
+    on_dev = row_logit_errors(oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=dev_batch_H), exp_rows)
+    factor = 2.0
+    return {"oracle_noise": pooled, "oracle_on_dev_H": on_dev, "factor": factor,
+            "enc_err_rel": float(np.abs(delta).max() / max(1e-30, np.abs(ref_batch_H).max())),
+            "enc_rms_rel": float(np.sqrt((delta ** 2).mean()) / max(1e-30, np.sqrt((ref_batch_H ** 2).mean()))),
+            "p50": factor * float(np.quantile(pooled, 0.5)), "p90": factor * float(np.quantile(pooled, 0.9)),
+            "max": factor * float(pooled.max())}

@@ -27,8 +27,9 @@ def _page(seed, H, W):
 
 @pytest.mark.parametrize("hw", [(128, 160), (256, 192)])
 def test_east_forward_f32_matches_oracle(setup, hw):
-    """fp32 parity mode: tolerance 1e-4 absolute on the sigmoid score map, 1e-3 relative-to-max on
-    geometry; summation order differs from oneDNN, BN is folded."""
+    """fp32 parity mode: tolerance 1e-4 absolute on the sigmoid score map, 2.5e-6 of max|geo| on the geometry (conftest.GEO_RTOL =
+    2x the measured error); summation order differs from oneDNN, BN is folded."""
+    from conftest import assert_maps_close
     from manuscript_ocr_amd.detectors._east.net import EastNet
     from oracle import imgproc
     sd, ref_net = setup
@@ -42,10 +43,8 @@ def test_east_forward_f32_matches_oracle(setup, hw):
     torch.cuda.synchronize()
     rs, rg = ref["score"][:, 0].numpy(), ref["geometry"].permute(0, 2, 3, 1).numpy()
     assert score.shape == rs.shape and geo.shape == rg.shape
-    es = np.abs(score.cpu().numpy() - rs).max()
-    eg = np.abs(geo.cpu().numpy() - rg).max() / max(np.abs(rg).max(), 1.0)
     assert rs.std() > 0.01, "degenerate score map: weights do not exercise the network"
-    assert es < 1e-4 and eg < 1e-3, (es, eg)
+    es, eg = assert_maps_close(score.cpu().numpy(), geo.cpu().numpy(), rs, rg, f"east {hw}")
     # identical candidate set at the default threshold
     assert np.array_equal(score.cpu().numpy() > np.float32(0.6), rs > np.float32(0.6)) or es < 1e-5
 

@@ -120,6 +120,90 @@ def test_conv3x3_winograd_vs_direct_and_f64(ops, case, form, monkeypatch):
     assert torch.all(big[..., :32] == 7.0)
 
 
+SPLIT_1X1_CASES = [
+    # M(pixels as N,H,W), Cin, Cout, relu, residual, in_ld_extra
+    ((2, 9, 13), 64, 128, True, False, 0),
+    ((1, 300, 1), 512, 1024, False, False, 0),      # the LSTM / linear GEMM form, M not a multiple of the tile
+    ((3, 8, 25), 256, 64, True, True, 0),           # Cout = 64: the 128 x 64 tile
+    ((1, 17, 5), 384, 256, True, False, 128),       # input read from a channel slice of a wider buffer (concat)
+    ((2, 4, 13), 2048, 512, False, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_1X1_CASES)
+def test_conv1x1_split_vs_exact_and_f64(ops, case):
+    """Split-operand 1x1 convolution (csrc/conv_split.hip: each f32 operand = three bf16 terms, six products on the bf16 matrix
+    pipes, f32 accumulate) against an f64 product: the same 2e-5 bound as the exact-f32 kernel and within 2x of that kernel's own
+    error (+ 1e-6) — i.e. the three dropped cross terms (<= 2^-25 of a product) do not show."""
+    (N, H, W), Cin, Cout, relu, use_res, extra = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    xw = torch.randn(N, H, W, Cin + extra, generator=g)
+    x = xw[..., extra:]
+    w = torch.randn(Cout, 1, 1, Cin, generator=g) * (2.0 / Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, H, W, Cout, generator=g) if use_res else None
+    ref = x.double().reshape(-1, Cin) @ w.view(Cout, Cin).double().t() + b.double()
+    if use_res:
+        ref = ref + res.double().reshape(-1, Cout)
+    if relu:
+        ref = torch.relu(ref)
+    xd = xw.cuda()[..., extra:]
+    rd = res.cuda() if use_res else None
+    w_e = w.cuda()
+    w_s = ops.attach_split(w.cuda(), True)
+    assert w_s._msocr_split.shape == (3, Cout, 1, 1, Cin) and w_s._msocr_split.dtype == torch.bfloat16
+    assert torch.equal(w_s._msocr_split.float().sum(0).cpu(), w)  # the planes add up to the weight exactly
+    out_e = ops.conv2d(xd, w_e, b.cuda(), relu=relu, residual=rd)
+    big = torch.full((N, H, W, Cout + 32), 7.0, device="cuda")
+    ops.PROFILE = []
+    ops.conv2d(xd, w_s, b.cuda(), relu=relu, residual=rd, out=big[..., 32:])
+    tags = [t[4][3] for t in ops.PROFILE]
+    ops.PROFILE = None
+    assert tags == ["direct_split"], tags
+    torch.cuda.synchronize()
+    scale = max(ref.abs().max().item(), 1.0)
+    e_e = (out_e.cpu().double().reshape(-1, Cout) - ref).abs().max().item()
+    e_s = (big[..., 32:].cpu().double().reshape(-1, Cout) - ref).abs().max().item()
+    print(f"conv1x1 split {case}: exact err {e_e / scale:.2e}, split err {e_s / scale:.2e}")
+    assert e_s <= 2e-5 * scale and e_s <= 2 * e_e + 1e-6 * scale, (e_s, e_e, scale)
+    assert torch.all(big[..., :32] == 7.0)
+
+
+@pytest.mark.parametrize("case", [(3, 4, 13, 512, 512, False, False), (2, 8, 25, 256, 256, True, True), (1, 17, 9, 128, 192, True, False),
+                                  (2, 12, 16, 160, 64, False, True)])
+def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
+    """Tall Winograd with the 24 transform-domain GEMMs on the split-operand kernel against an f64 convolution: 2e-5 bound, within
+    2x of the exact-f32 Winograd path's own error."""
+    monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
+    N, H, W, Cin, Cout, relu, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
+    w_e = ops.attach_winograd(_w_khwc(w, torch.float32), False)
+    w_s = ops.attach_winograd(_w_khwc(w, torch.float32), True)
+    assert not hasattr(w_e, "_msocr_wino42_split") and w_s._msocr_wino42_split.shape == (3, 24, Cout, Cin)
+    out_e = ops.conv2d(xd, w_e, b.cuda(), (1, 1), (1, 1), relu, rd)
+    ops.PROFILE = []
+    out_s = ops.conv2d(xd, w_s, b.cuda(), (1, 1), (1, 1), relu, rd)
+    tags = [t[4][3] for t in ops.PROFILE if t[2] == "conv_gemm"]
+    ops.PROFILE = None
+    assert tags == ["winograd42_split"], tags
+    torch.cuda.synchronize()
+    scale = max(ref.abs().max().item(), 1.0)
+    e_e = (out_e.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    e_s = (out_s.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    print(f"winograd42 split {case}: exact err {e_e / scale:.2e}, split err {e_s / scale:.2e}")
+    assert e_s <= 2e-5 * scale and e_s <= 2 * e_e + 1e-6 * scale, (e_s, e_e, scale)
+
+
 FUSED64_CASES = [
     # N, H, W, Cout, relu, residual, pool2     (Cin = 64)
     (3, 32, 100, 128, True, False, True),    # TRBA conv0b + MaxPool2d(2, 2)
