@@ -29,7 +29,7 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp32": 157.3, "fp32-exact": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 TRBA_CFG = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
 STEP_TIMES = [] if os.environ.get("MSOCR_STEP_TIMES") else None  # diagnostics: host time after every collected step
 TIE_TOL = 5e-3  # first-step logit gap (|logit| ~ 5) treated as a tie between two f32 implementations (tests/conftest.py)
@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pipeline", choices=["east", "pipeline"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="conv storage/MFMA input type; fp32 = parity mode (text identical to the CPU reference)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-exact", "bf16"],
+                    help="fp32 = parity mode (text identical to the CPU reference): f32 tensors, 1x1 / Winograd-domain GEMMs with operands split "
+                         "exactly into three bf16 terms; fp32-exact = exact-f32 MFMA in every layer; bf16 = throughput mode (not a parity mode)")
     ap.add_argument("--pages", type=int, default=0, help="pages per step per GPU (default 16 pipeline / 8 east)")
     ap.add_argument("--height", type=int, default=1536)
     ap.add_argument("--width", type=int, default=2048)
@@ -66,7 +67,7 @@ def parse():
     return ap.parse_args()
 
 
-CONV_STAGE_KERNELS = ("conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel",
+CONV_STAGE_KERNELS = ("conv_igemm_kernel", "conv_split_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel",
                       "wino42_fused64_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
@@ -91,7 +92,7 @@ def live_pmc_traffic(a):
             cmd += [flag, str(val)]
     if a.graphs:
         cmd.append("--graphs")
-    steps = 4.0
+    steps = None  # steps the child executed: reported by the child itself ("[bench] steps_executed N" on stderr)
     kib = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
         d = tempfile.mkdtemp(prefix="msocr_pmc_", dir="/tmp")
@@ -106,8 +107,14 @@ def live_pmc_traffic(a):
             except subprocess.TimeoutExpired:
                 import signal
                 os.killpg(proc.pid, signal.SIGKILL)
-                proc.wait()
-                return None, f"rocprofv3 --pmc {counter}: no result within 300 s (killed)"
+                _, err = proc.communicate()
+                # an overrunning pass is a fault, not a skipped measurement: the line carries the flag and the child's last words
+                return None, (f"pmc_pass_killed: rocprofv3 --pmc {counter} gave no result within 300 s and was killed; child stderr tail: "
+                              + (err or b"").decode(errors="replace")[-400:])
+            import re
+            m_steps = re.findall(r"\[bench\] steps_executed (\d+)", err.decode(errors="replace"))
+            if m_steps:
+                steps = float(m_steps[-1])
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if proc.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
@@ -133,6 +140,8 @@ def live_pmc_traffic(a):
             return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    if steps is None:
+        return None, "the PMC child runs did not report their step count"
     names = sorted(set(kib["FETCH_SIZE"]) | set(kib["WRITE_SIZE"]))
     per_kernel = {n: (2.0 * kib["FETCH_SIZE"].get(n, 0.0) + kib["WRITE_SIZE"].get(n, 0.0)) * 1024.0 / steps for n in names}
     mf = kib.get("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE")
@@ -142,10 +151,16 @@ def live_pmc_traffic(a):
             b = sum(v[0] for n, v in mf.items() if pred(n))
             g = sum(v[1] for n, v in mf.items() if pred(n))
             ns = sum(v[2] for n, v in mf.items() if pred(n))
+            # FLOP per busy cycle of one SIMD's matrix pipe: exact-f32 MFMA 64; v_mfma_f32_32x32x16_bf16 1024 (32768 FLOP in 32 cycles),
+            # of which a split launch needs 6 per f32-equivalent FLOP
+            pipe = sum(v[0] * (1024.0 if n.startswith("conv_split_kernel") else 64.0) for n, v in mf.items() if pred(n))
+            equiv = sum(v[0] * (1024.0 / 6.0 if n.startswith("conv_split_kernel") else 64.0) for n, v in mf.items() if pred(n))
             return {"mfma_pipe_busy_fraction": b / (g / 8.0 * 1024.0), "clock_ghz": g / 8.0 / ns,
-                    "executed_mfma_tflops": b * 64.0 / (ns * 1e-9) / 1e12, "kernel_ms_per_step": ns / steps / 1e6} if g > 0 else None
+                    "executed_mfma_tflops": pipe / (ns * 1e-9) / 1e12, "f32_equivalent_tflops": equiv / (ns * 1e-9) / 1e12,
+                    "kernel_ms_per_step": ns / steps / 1e6} if g > 0 else None
         mfma = {"conv_stage": util(lambda n: True),
-                "gemm_kernels": util(lambda n: n.startswith(("conv_igemm_kernel", "wino42_fused64_kernel", "wino_gemm4_kernel"))),
+                "gemm_kernels": util(lambda n: n.startswith(("conv_igemm_kernel", "conv_split_kernel", "wino42_fused64_kernel", "wino_gemm4_kernel"))),
+                "split_gemm_kernel": util(lambda n: n.startswith("conv_split_kernel")),
                 "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 x 1024 SIMDs), one rocprofv3 --pmc "
                             "pass with --serialize-streams; conv_stage = GEMM kernels + Winograd transforms, gemm_kernels = without them"}
     return {"hbm_bytes_per_step": sum(per_kernel.values()), "per_kernel_bytes_per_step": per_kernel, "mfma_pmc": mfma,
@@ -162,7 +177,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     live_traffic, live_note = None, "not requested"
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)  # no profiler inside a profiled run
-    if world == 1 and not (a.no_live_traffic or a.no_roofline or a.serialize_streams or under_profiler) and a.precision == "fp32":
+    if world == 1 and not (a.no_live_traffic or a.no_roofline or a.serialize_streams or under_profiler) and a.precision != "bf16":
         t_pmc = time.time()
         live_traffic, live_note = live_pmc_traffic(a)  # child processes; this process has not touched the GPU yet
         print(f"[bench] live PMC traffic passes: {live_note}, {time.time() - t_pmc:.0f} s", file=sys.stderr)
@@ -257,7 +272,13 @@ def main():
             out_ = east_collect(q.pop(0))
         return out_
 
+    executed_steps = [0]
+
     def run_steps(k):
+        executed_steps[0] += k
+        return _run_steps(k)
+
+    def _run_steps(k):
         """k steps, software-pipelined across steps: the detector work of step i+1 is enqueued and its host stage
         (box filters, reading order, crop descriptors -> recogniser enqueue) runs BEFORE step i is collected, so the
         device always holds queued recogniser work while the host annotates step i.  All work of the k steps is inside."""
@@ -350,7 +371,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "bf16"}[a.precision],
+        "dtype": {"fp32": "f32 (bf16x3 split operands on the 1x1 / Winograd-domain GEMMs, f32 accumulate)", "fp32-exact": "f32", "bf16": "bf16"}[a.precision],
         "data": "synthetic" + (", host pages uploaded every step (PCIe-inclusive)" if a.host_pages else ""),
         "config": {
             "workload": (f"full EAST->crop->TRBA pipeline (BASELINE configs[3]): batch={NP} pages @ {W}x{H} per GPU, "
@@ -420,29 +441,54 @@ def main():
         #     kernels sharing the chip.  Chip-level rate = FLOP / union of the intervals in which >= 1 conv-stage kernel runs.
         by = instrumented(a.serialize_streams)
         gemm = by["conv_gemm"]
-        executed = float(sum(w[1] for _, _, w, _ in gemm))
+        BF16_PEAK = PEAK_TFLOPS["bf16"]
+
+        def is_split(tag):  # launches of conv_split_kernel: f32 operands as three bf16 terms, six bf16 MFMA products per f32 product
+            return bool(tag) and str(tag[3]).endswith("_split")
+
+        def pipe_seconds(recs):
+            """Time the recorded GEMM launches would take with the matrix pipe each one uses at its dense peak: exact-f32 launches at
+            157.3 TFLOP/s on the FLOP they execute, split launches at 2.5 PFLOP/s on 6x their f32-equivalent FLOP."""
+            if a.precision == "bf16":
+                return sum(w[1] for _, _, w, _ in recs) / (BF16_PEAK * 1e12)
+            return sum((6.0 * w[1] / (BF16_PEAK * 1e12)) if is_split(t) else (w[1] / (PEAK_TFLOPS["fp32"] * 1e12)) for _, _, w, t in recs)
+
+        executed = float(sum(w[1] for _, _, w, _ in gemm))       # f32-equivalent FLOP the GEMM launches execute (Winograd: transform domain)
+        ex_split = float(sum(w[1] for _, _, w, t in gemm if is_split(t)))
         algorithmic = float(sum(w[0] for _, _, w, _ in gemm))
         stage_ms = union_ms([(s_, e_) for k in CONV for s_, e_, _, _ in by.get(k, [])])
         gemm_ms = union_ms([(s_, e_) for s_, e_, _, _ in gemm])
+        floor_s = pipe_seconds(gemm)
+        peak = executed / floor_s / 1e12  # f32-equivalent TFLOP/s of this launch mix with every matrix pipe at its dense peak
         res["roofline"] = {
-            "kernel": "conv_igemm_kernel (implicit-GEMM convolution on the f32 matrix cores: direct convolutions, 1x1 layers, the "
-                      "LSTM/linear GEMMs and the 24-GEMM launch of every Winograd F(4,3)xF(2,3) layer), over the convolution stage = "
-                      "those launches + the Winograd transform kernels around them",
+            "kernel": "conv_split_kernel + conv_igemm_kernel (GEMM-shaped convolution work on the matrix cores: the 24-GEMM launch of every "
+                      "Winograd F(4,3)xF(2,3) layer and the 1x1 layers with f32 operands split exactly into three bf16 terms on "
+                      "v_mfma_f32_32x32x16_bf16 (six products per f32 product, f32 accumulate); strided / 7x7 / 2x2 convolutions and the "
+                      "LSTM / linear GEMMs on exact-f32 MFMA), over the convolution stage = those launches + the Winograd transform kernels",
             "bound": "mfma",
             "achieved": executed / (stage_ms * 1e-3) / 1e12,
             "peak": peak,
             "unit": "TFLOP/s",
-            "frac": executed / (stage_ms * 1e-3) / 1e12 / peak,
-            "definition": "achieved = FLOP the MFMAs EXECUTE (Winograd layers: 2*24*tiles*Cin*Cout per 4x2-output tile, 3x fewer "
-                          "than the direct form) / time in which at least one conv-stage kernel is executing (HIP events on the launch streams, "
-                          "sub-batch streams overlapping as in the timed region); <= 1 by construction",
-            "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": executed / (gemm_ms * 1e-3) / 1e12 / peak,
+            "frac": floor_s * 1e3 / stage_ms,
+            "definition": "achieved = f32-equivalent FLOP the GEMM launches execute (Winograd layers: 2*24*tiles*Cin*Cout per 4x2-output "
+                          "tile, 3x fewer than the direct form) / time in which at least one conv-stage kernel is executing (HIP events on "
+                          "the launch streams, sub-batch streams overlapping as in the timed region); peak = the same FLOP / the time the "
+                          "launches need with the matrix pipe each one uses at its dense peak (split launches: 6 bf16 FLOP per f32-equivalent "
+                          "FLOP at 2500 TFLOP/s = 416.7 f32-equivalent; exact-f32 launches: 157.3); frac = achieved / peak = matrix-pipe "
+                          "utilisation of the stage, <= 1 by construction",
+            "split_bf16x3": {"share_of_executed_flop": ex_split / executed if executed else 0.0,
+                             "bf16_pipe_tflops_over_stage": 6.0 * ex_split / (stage_ms * 1e-3) / 1e12,
+                             "bf16_pipe_frac_over_stage": 6.0 * ex_split / (stage_ms * 1e-3) / 1e12 / BF16_PEAK,
+                             "f32_pipe_tflops_over_stage": (executed - ex_split) / (stage_ms * 1e-3) / 1e12},
+            "vs_f32_mfma_peak": executed / (stage_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"],
+            "gemm_kernel_only": {"achieved": executed / (gemm_ms * 1e-3) / 1e12, "frac": floor_s * 1e3 / gemm_ms,
                                  "busy_ms_per_step": gemm_ms / a.steps},
             "algorithmic_equiv_tflops": algorithmic / (stage_ms * 1e-3) / 1e12,
             # HBM bytes per step of the convolution stage, PMC counters of this invocation (live_pmc_traffic); null if not measured
             "traffic": live_traffic["hbm_bytes_per_step"] if live_traffic else None,
             "traffic_unit": "bytes per step, convolution-stage kernels (2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction)",
             "traffic_note": live_note,
+            "pmc_pass_killed": str(live_note).startswith("pmc_pass_killed"),
             "traffic_detail": ({k: live_traffic[k] for k in ("per_kernel_bytes_per_step", "counters", "measured_in_this_run")}
                                if live_traffic else None),
             "mfma_pmc": live_traffic["mfma_pmc"] if live_traffic else None,
@@ -460,20 +506,22 @@ def main():
         gemm = by["conv_gemm"]
         dur = np.array([e_ - s_ for s_, e_, _, _ in gemm])
         ex2 = float(sum(w[1] for _, _, w, _ in gemm))
-        res["roofline"]["isolated"] = {"achieved": ex2 / (dur.sum() * 1e-3) / 1e12, "frac": ex2 / (dur.sum() * 1e-3) / 1e12 / peak,
+        floor2_s = pipe_seconds(gemm)
+        res["roofline"]["isolated"] = {"achieved": ex2 / (dur.sum() * 1e-3) / 1e12, "frac": floor2_s * 1e3 / float(dur.sum()),
                                        "avg_launch_ms": float(dur.mean()), "gemm_ms_per_step": float(dur.sum() / a.steps),
                                        "conv_stage_ms_per_step": float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])) / a.steps)}
         HBM_PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
         # the stage priced kernel by kernel at each kernel's OWN bound: GEMM launches at the f32 MFMA peak on the FLOP they execute,
         # Winograd transforms at the HBM peak on their algorithmic bytes — the floor of the stage's time with this algorithm mix
         tr_bytes = float(sum(w for k in ("wino_in", "wino_out") for _, _, w, _ in by.get(k, [])))
-        floor_ms = (ex2 / (peak * 1e12) + tr_bytes / (HBM_PEAK * 1e9)) * 1e3
+        floor_ms = (floor2_s + tr_bytes / (HBM_PEAK * 1e9)) * 1e3
         iso_ms = float(sum(e_ - s_ for k in CONV for s_, e_, _, _ in by.get(k, [])))
         res["roofline"]["mixed_bound"] = {
             "floor_ms_per_step": floor_ms / a.steps, "frac_isolated": floor_ms / iso_ms, "frac": floor_ms / stage_ms,
             "transform_gbytes_per_step": tr_bytes / a.steps / 1e9,
-            "definition": "floor = executed GEMM FLOP / 157.3 TFLOP/s + algorithmic bytes of the Winograd transforms / 8 TB/s; frac = floor / "
-                          "conv-stage-busy time of the overlapped run, frac_isolated = floor / summed isolated launch durations"}
+            "definition": "floor = GEMM launches at the dense peak of the matrix pipe each one uses (roofline.definition) + algorithmic bytes "
+                          "of the Winograd transforms / 8 TB/s; frac = floor / conv-stage-busy time of the overlapped run, frac_isolated = "
+                          "floor / summed isolated launch durations"}
         names = {"wino_in": "wino42_input_kernel", "wino_out": "wino42_output_kernel", "se_residual": "se_residual_kernel",
                  "maxpool": "maxpool_kernel", "bilstm": "bilstm_kernel", "attn_beam": "attn_beam_mfma_kernel"}
         mean_run = (rec.last_run_length_sum / rec.last_rows) if (rec is not None and getattr(rec, "last_rows", 0)) else None
@@ -523,6 +571,7 @@ def main():
             print(f"[phase] {rec_[0]:8s} {1e3 * (rec_[1] - t00):9.1f} .. {1e3 * (rec_[2] - t00):9.1f} ms  ({1e3 * (rec_[2] - rec_[1]):6.1f})"
                   + (f"  {rec_[3]}" if len(rec_) > 3 else ""), file=sys.stderr)
     if rank == 0:
+        print(f"[bench] steps_executed {executed_steps[0]}", file=sys.stderr)  # read by live_pmc_traffic of a parent run
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

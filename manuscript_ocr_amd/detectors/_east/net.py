@@ -20,6 +20,76 @@ LAYERS = (("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2), ("
 BN_EPS = 1e-5
 
 
+def expected_state_shapes():
+    """Key -> shape of the inference model's state_dict (reference EAST(backbone_name="resnet50"), east.py:108-127:
+    torchvision ResNet-50 trunk without fc under `backbone.extractor.`, FeatureMergingBranchResNet, OutputHead)."""
+    shapes = {}
+
+    def conv(k, co, ci, kh, kw, bias=False):
+        shapes[k + ".weight"] = (co, ci, kh, kw)
+        if bias:
+            shapes[k + ".bias"] = (co,)
+
+    def bn(k, c):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            shapes[f"{k}.{n}"] = (c,)
+
+    p = "backbone.extractor."
+    conv(p + "conv1", 64, 3, 7, 7), bn(p + "bn1", 64)
+    inplanes = 64
+    for lname, planes, blocks, _ in LAYERS:
+        for b in range(blocks):
+            q = f"{p}{lname}.{b}."
+            conv(q + "conv1", planes, inplanes, 1, 1), bn(q + "bn1", planes)
+            conv(q + "conv2", planes, planes, 3, 3), bn(q + "bn2", planes)
+            conv(q + "conv3", planes * 4, planes, 1, 1), bn(q + "bn3", planes * 4)
+            if b == 0:
+                conv(q + "downsample.0", planes * 4, inplanes, 1, 1), bn(q + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    for k, (cin, mid, cout) in enumerate(((2048, 512, 512), (1536, 256, 256), (768, 128, 128), (384, 64, 32)), start=1):
+        q = f"decoder.block{k}."
+        conv(q + "conv1x1.0", mid, cin, 1, 1, True), bn(q + "conv1x1.1", mid)
+        conv(q + "conv3x3.0", cout, mid, 3, 3, True), bn(q + "conv3x3.1", cout)
+    conv("output_head.score_map", 1, 32, 1, 1, True)
+    conv("output_head.geo_map", 8, 32, 1, 1, True)
+    return shapes
+
+
+def complete_state_dict(state_dict, seed=0):
+    """`load_state_dict(state, strict=False)` as the reference loads its detector (east.py:130-133): unexpected keys (a ResNet-101
+    training checkpoint's layer3.6-22, num_batches_tracked, an fc head) are ignored; a MISSING key keeps what a freshly constructed
+    module holds — PyTorch's default initialisation (Conv2d: kaiming_uniform(a = sqrt 5) = U(+-1/sqrt(fan_in)) for weight and bias;
+    BatchNorm2d: weight 1, bias 0, running_mean 0, running_var 1), drawn here from a seeded generator; a key of the wrong shape
+    raises RuntimeError, as load_state_dict does even when strict=False.  Returns (complete dict, missing keys, unexpected keys)."""
+    shapes = expected_state_shapes()
+    sd = {}
+    g = torch.Generator().manual_seed(seed)
+    missing, bad = [], []
+    for k, shp in shapes.items():
+        v = state_dict.get(k)
+        if v is not None:
+            if tuple(v.shape) != shp:
+                bad.append(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, the shape in current model is {shp}")
+                continue
+            sd[k] = v
+            continue
+        missing.append(k)
+        if k.endswith("running_mean") or (k.endswith(".bias") and len(shp) == 1 and k[: -len(".bias")] + ".running_mean" in shapes):
+            sd[k] = torch.zeros(shp)
+        elif k.endswith("running_var") or (k.endswith(".weight") and len(shp) == 1):
+            sd[k] = torch.ones(shp)
+        else:
+            wk = k[: k.rfind(".")] + ".weight"
+            fan_in = shapes[wk][1] * shapes[wk][2] * shapes[wk][3]
+            bound = 1.0 / fan_in ** 0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+    if bad:
+        raise RuntimeError("Error(s) in loading state_dict for EAST:\n\t" + "\n\t".join(bad))
+    nbt = ".num_batches_tracked"  # a BatchNorm2d buffer of the module itself: expected, unused at inference
+    unexpected = [k for k in state_dict if k not in shapes and not (k.endswith(nbt) and k[: -len(nbt)] + ".running_mean" in shapes)]
+    return sd, missing, unexpected
+
+
 def fold_bn(w, conv_bias, prefix_bn, sd):
     """conv (OIHW f32) followed by eval-mode BatchNorm -> (w', b') in f32."""
     gamma, beta = sd[prefix_bn + ".weight"].float(), sd[prefix_bn + ".bias"].float()
@@ -60,7 +130,7 @@ class EastNet:
     def __init__(self, state_dict, dtype=torch.float32, device="cuda", split=None):
         """split: None = ops.SPLIT_BF16X3 (default on), False = exact-f32 MFMA for every f32 layer (precision="fp32-exact")."""
         self.dtype, self.device = dtype, torch.device(device)
-        sd = {k: v for k, v in state_dict.items()}
+        sd, self.missing_keys, self.unexpected_keys = complete_state_dict(state_dict)  # strict=False, as east.py:130-133
         P = {}
 
         def conv_bn(name_conv, name_bn, bias_key=None):

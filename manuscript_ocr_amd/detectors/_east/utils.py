@@ -4,8 +4,8 @@
   resolve_intersections                      <- :500-547
   sort_boxes_reading_order                   <- :550-607
   sort_boxes_reading_order_with_resolutions  <- :610-644
-  visualize_page                             <- :42-220 (minimal PIL renderer; the reference's
-                                                cv2 drawing is out of the hot-path scope)
+  draw_quads / visualize_page                <- :42-220 (same parameters and output contract; cv2's fillPoly /
+                                                GaussianBlur / polylines restated with PIL + NumPy)
 cv2 is not a dependency here: files are decoded with PIL (RGB), which is the reference's own
 fallback branch.
 """
@@ -103,18 +103,79 @@ def sort_boxes_reading_order_with_resolutions(boxes, y_tol_ratio=0.6, x_gap_rati
     return [back[b] for b in sort_boxes_reading_order(shrunk, y_tol_ratio, x_gap_ratio)]
 
 
-def visualize_page(image, page, show_order=False, color=(0, 200, 0), width=2):
-    """Draw word polygons (and reading-order indices) on a copy of the image -> PIL.Image."""
-    pil = image.copy() if isinstance(image, Image.Image) else Image.fromarray(np.asarray(image))
-    pil = pil.convert("RGB")
-    draw = ImageDraw.Draw(pil)
-    k = 0
+def _gaussian_blur_f32(mask, k):
+    """cv2.GaussianBlur(mask, (k, k), 0) restated: separable kernel exp(-(x - c)^2 / (2 sigma^2)) normalised to 1 with OpenCV's
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8 for a non-positive sigma argument, BORDER_REFLECT_101 (parity unpinned: cv2 absent;
+    OpenCV uses fixed tables for k <= 7, which the default k = 11 does not hit)."""
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    x = np.arange(k, dtype=np.float64) - (k - 1) / 2
+    g = np.exp(-(x * x) / (2 * sigma * sigma))
+    g = (g / g.sum()).astype(np.float32)
+    r = k // 2
+    h, w = mask.shape
+    if h <= r or w <= r:  # reflect_101 needs at least r + 1 samples; tiny images: clamp instead
+        padded = np.pad(mask, r, mode="edge")
+    else:
+        padded = np.pad(mask, r, mode="reflect")
+    tmp = np.zeros((h + 2 * r, w), dtype=np.float32)
+    for i in range(k):
+        tmp += g[i] * padded[:, i:i + w]
+    out = np.zeros((h, w), dtype=np.float32)
+    for i in range(k):
+        out += g[i] * tmp[i:i + h, :]
+    return out
+
+
+def draw_quads(image, quads, color=(0, 0, 0), thickness=1, dark_alpha=0.5, blur_ksize=11):
+    """The reference's overlay style (detectors/_east/utils.py:42-92): the page darkened by `dark_alpha` outside the quads, the
+    inside kept at full brightness through a Gaussian-blurred polygon mask, quad outlines on top.  -> PIL.Image (RGB).
+    cv2.fillPoly / GaussianBlur / polylines are restated with PIL + NumPy (cv2 is not a dependency here); vertex coordinates are
+    truncated to int32 as the reference does."""
+    img = np.asarray(image).copy()
+    if quads is None or len(quads) == 0:
+        return Image.fromarray(img)
+    quads = np.asarray(quads)
+    h, w = img.shape[:2]
+    dark_bg = (img.astype(np.float32) * (1 - dark_alpha)).astype(np.uint8)
+    mask_img = Image.new("L", (w, h), 0)
+    md = ImageDraw.Draw(mask_img)
+    polys = [[(int(x), int(y)) for x, y in np.asarray(q[:8]).reshape(4, 2).astype(np.int32)] for q in quads]
+    for pts in polys:
+        md.polygon(pts, fill=1, outline=1)
+    k = blur_ksize if blur_ksize % 2 == 1 else blur_ksize + 1
+    mask = np.clip(_gaussian_blur_f32(np.asarray(mask_img, dtype=np.float32), k), 0.0, 1.0)[:, :, None]
+    out = img.astype(np.float32) * mask + dark_bg.astype(np.float32) * (1 - mask)
+    out_img = Image.fromarray(np.clip(out, 0, 255).astype(np.uint8))
+    d = ImageDraw.Draw(out_img)
+    for pts in polys:
+        d.line(pts + [pts[0]], fill=tuple(int(c) for c in color), width=int(thickness))
+    return out_img
+
+
+def visualize_page(image, page, *, show_order=False, color=(0, 0, 255), thickness=2, dark_alpha=0.3, blur_ksize=11,
+                   line_color=(0, 255, 0), number_color=(255, 255, 255), number_bg=(0, 0, 0)):
+    """Drop-in for the reference's visualize_page (detectors/_east/utils.py:95-220): same keyword-only parameters and defaults,
+    same output contract — an RGB PIL image of the page's size with every word's quad drawn in the EAST overlay style
+    (draw_quads) and, with show_order, green lines joining consecutive word centres plus a numbered 24 x 24 box (1-based) at each
+    centre.  A page without words returns the input itself (PIL input) or Image.fromarray(input)."""
+    img = np.array(image.convert("RGB")) if isinstance(image, Image.Image) else np.asarray(image).copy()
+    quads, words = [], []
     for block in page.blocks:
         for w in block.words:
-            pts = [(float(x), float(y)) for x, y in w.polygon]
-            if len(pts) >= 2:
-                draw.line(pts + [pts[0]], fill=color, width=width)
-            if show_order and pts:
-                draw.text(pts[0], str(k), fill=(220, 0, 0))
-            k += 1
-    return pil
+            quads.append(np.array(w.polygon).reshape(-1))
+            words.append(w)
+    if not quads:
+        return Image.fromarray(img) if isinstance(image, np.ndarray) else image
+    out = draw_quads(img, np.stack(quads, axis=0), color=color, thickness=thickness, dark_alpha=dark_alpha, blur_ksize=blur_ksize)
+    if show_order:
+        draw = ImageDraw.Draw(out)
+        centers = []
+        for w in words:
+            xs, ys = [p[0] for p in w.polygon], [p[1] for p in w.polygon]
+            centers.append((sum(xs) / len(xs), sum(ys) / len(ys)))
+        for p, c in zip(centers, centers[1:]):
+            draw.line([p, c], fill=line_color, width=3)
+        for idx, (cx, cy) in enumerate(centers, start=1):
+            draw.rectangle([cx - 12, cy - 12, cx + 12, cy + 12], fill=number_bg)
+            draw.text((cx - 6, cy - 8), str(idx), fill=number_color)
+    return out

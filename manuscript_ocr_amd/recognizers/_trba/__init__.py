@@ -23,6 +23,28 @@ from .net import TrbaNet
 from .transforms import decode_tokens, load_charset, resize_and_pad
 
 
+class _GraphLease:
+    """Holds one captured recogniser-graph instance for a handle; released by recognize_finish (also when it raises) or when the
+    handle is dropped without ever being finished."""
+
+    def __init__(self, inst):
+        self.inst = inst
+
+    def release(self):
+        if self.inst is not None:
+            self.inst["busy"] = False
+            self.inst = None
+
+    def __del__(self):
+        if self.inst is not None:
+            try:
+                torch.cuda.synchronize()  # the replay may still be running: its static buffers must not be rewritten under it
+            except Exception:
+                pass
+            self.inst["busy"] = False
+            self.inst = None
+
+
 class TRBA:
     _DEFAULT_PRESET_NAME = "exp_1_baseline"
     _DEFAULT_STORAGE_ROOT = Path.home() / ".manuscript" / "trba"
@@ -37,6 +59,7 @@ class TRBA:
         config = kwargs.pop("config", None)
         self.device_batch = int(kwargs.pop("device_batch", 2048))
         self.use_graphs = bool(kwargs.pop("use_graphs", False))  # hipGraph replay of crop + encode + beam decode (recognize_start_graph)
+        self.graph_cache_buckets = int(kwargs.pop("graph_cache_buckets", 8))  # captured (stream, pages, row bucket) keys kept
         self._graphs: Dict[Any, Dict[str, Any]] = {}
         if kwargs:
             raise TypeError(f"Unexpected keyword argument(s): {', '.join(kwargs.keys())}")
@@ -222,7 +245,16 @@ class TRBA:
         # one pool per launch stream: the groups of a batch are in flight together, each replays its own instances
         key = (torch.cuda.current_stream().cuda_stream, pages_dev.data_ptr(), tuple(pages_dev.shape), Mcap, nch_cap, batch_size, beam_size,
                float(temperature), float(alpha))
-        pool = self._graphs.setdefault(key, {"warm": False, "inst": []})
+        pool = self._graphs.pop(key, None) or {"warm": False, "inst": []}
+        self._graphs[key] = pool  # most recently used last
+        # bounded cache: the key holds the page tensor's address, so callers whose pages move would otherwise capture
+        # without end, each instance pinning a private pool of up to device_batch crops of activations.  Least recently used
+        # buckets whose instances are all idle are dropped.
+        while len(self._graphs) > self.graph_cache_buckets:
+            victim = next((k for k, v in self._graphs.items() if k != key and not any(i["busy"] for i in v["inst"])), None)
+            if victim is None:
+                break
+            del self._graphs[victim]
         if not pool["warm"]:
             pool["warm"] = True
             return None
@@ -272,7 +304,8 @@ class TRBA:
             meta_dev.record_stream(cur)
         inst["meta"].copy_(meta_dev, non_blocking=True)
         inst["graph"].replay()
-        return {"parts": [inst["part"]], "N": Mcap, "M_real": M, "mode": "beam", "beam": beam_size, "bounds": [(0, Mcap)], "graph_inst": inst}
+        return {"parts": [inst["part"]], "N": Mcap, "M_real": M, "mode": "beam", "beam": beam_size, "bounds": [(0, Mcap)],
+                "graph_inst": _GraphLease(inst)}
 
     def recognize_finish(self, handle, batch_size=32, spans=None, return_logits=False):
         """Phases 2-3 — derive the reference's per-chunk run lengths, back-track (beam) and reduce confidences.
@@ -281,6 +314,15 @@ class TRBA:
         (one page each); inside a span rows are chunked by `batch_size` and every chunk stops at its own step
         (greedy: first step where every row emits EOS; beam: once every beam of every row is finished) — that run
         length enters the confidences.  Only ids and one float per row cross PCIe (msocr_seq_confidence)."""
+        from ... import _native as nat
+        from ... import ops
+        try:
+            return self._recognize_finish(handle, batch_size, spans, return_logits)
+        finally:
+            if handle.get("graph_inst") is not None:  # also on an exception: the instance must not stay leased for ever
+                handle["graph_inst"].release()
+
+    def _recognize_finish(self, handle, batch_size, spans, return_logits):
         from ... import _native as nat
         from ... import ops
         parts, N, mode, beam_size = handle["parts"], handle["N"], handle["mode"], handle["beam"]
@@ -321,8 +363,6 @@ class TRBA:
             parts[k] = None
         ids_h = torch.cat(ids_out).cpu().numpy()[:M_real]
         conf_h = torch.cat(conf_out).cpu().numpy()[:M_real]
-        if handle.get("graph_inst") is not None:
-            handle["graph_inst"]["busy"] = False  # every output of the graph instance has been read back
         if return_logits:
             return ids_h, trun[:M_real], conf_h, np.concatenate(logit_out)[:M_real]
         return ids_h, trun[:M_real], conf_h

@@ -415,6 +415,7 @@ for c in $pmc; do
     GRBM_GUI_ACTIVE) row "void conv_igemm_kernel<float, 128>(ConvParams)" GRBM_GUI_ACTIVE 8000 0 1000; row "wino42_input_kernel(float const*)" GRBM_GUI_ACTIVE 8000 2000 3000;;
   esac
 done
+if [ -z "$MSOCR_TEST_NO_STEPS" ]; then echo "[bench] steps_executed 4" >&2; fi
 exit 0
 ''')
     stub.chmod(stub.stat().st_mode | stat.S_IEXEC)
@@ -431,3 +432,81 @@ exit 0
     m = res["mfma_pmc"]
     assert abs(m["gemm_kernels"]["mfma_pipe_busy_fraction"] - 512000 / (8000 / 8 * 1024)) < 1e-12
     assert abs(m["conv_stage"]["mfma_pipe_busy_fraction"] - 512000 / (16000 / 8 * 1024)) < 1e-12
+    # the step count comes from the child (its "[bench] steps_executed N" line), never from a constant kept by hand
+    monkeypatch.setenv("MSOCR_TEST_NO_STEPS", "1")
+    res2, note2 = bench.live_pmc_traffic(a)
+    assert res2 is None and "step count" in note2
+
+
+def test_east_loader_is_non_strict_like_the_reference():
+    """EAST loads its checkpoint with strict=False (reference east.py:130-133): a ResNet-101 training checkpoint (extra
+    layer3.6-22 blocks, num_batches_tracked buffers) loads into the ResNet-50 inference model, missing keys keep a fresh module's
+    default initialisation, a wrong shape raises RuntimeError (as load_state_dict does even when strict=False)."""
+    import torch
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.detectors._east.net import complete_state_dict, expected_state_shapes
+    sd = synth.east_state_dict(seed=3)
+    shapes = expected_state_shapes()
+    assert {k for k in sd if not k.endswith("num_batches_tracked")} == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    full, missing, unexpected = complete_state_dict(sd)
+    assert not missing and not unexpected and all(full[k] is sd[k] for k in shapes)
+    # ResNet-101 style: 17 extra layer3 blocks + bookkeeping buffers
+    r101 = dict(sd)
+    for b in range(6, 23):
+        for j, (co, ci, k) in enumerate(((256, 1024, 1), (256, 256, 3), (1024, 256, 1)), start=1):
+            r101[f"backbone.extractor.layer3.{b}.conv{j}.weight"] = torch.zeros(co, ci, k, k)
+            for n in ("weight", "bias", "running_mean", "running_var"):
+                r101[f"backbone.extractor.layer3.{b}.bn{j}.{n}"] = torch.zeros(co)
+            r101[f"backbone.extractor.layer3.{b}.bn{j}.num_batches_tracked"] = torch.tensor(7)
+    r101["backbone.extractor.bn1.num_batches_tracked"] = torch.tensor(7)
+    full, missing, unexpected = complete_state_dict(r101)
+    assert not missing and len(unexpected) == 17 * 3 * 6 and set(full) == set(shapes)
+    # missing keys: BN -> identity statistics, conv -> default-init range, nothing raised
+    part = {k: v for k, v in sd.items() if not k.startswith("decoder.block4.") and k != "backbone.extractor.bn1.running_var"}
+    full, missing, unexpected = complete_state_dict(part)
+    assert set(missing) == {k for k in shapes if k.startswith("decoder.block4.")} | {"backbone.extractor.bn1.running_var"}
+    assert torch.equal(full["backbone.extractor.bn1.running_var"], torch.ones(64))
+    assert torch.equal(full["decoder.block4.conv3x3.1.weight"], torch.ones(32)) and torch.equal(full["decoder.block4.conv3x3.1.bias"], torch.zeros(32))
+    assert torch.equal(full["decoder.block4.conv1x1.1.running_mean"], torch.zeros(64))
+    w = full["decoder.block4.conv3x3.0.weight"]
+    assert w.shape == (32, 64, 3, 3) and w.abs().max() <= 1 / (64 * 9) ** 0.5 and w.std() > 0.01
+    assert full["decoder.block4.conv1x1.0.bias"].abs().max() <= 1 / 384 ** 0.5
+    bad = dict(sd)
+    bad["output_head.geo_map.weight"] = torch.zeros(5, 32, 1, 1)
+    with pytest.raises(RuntimeError, match="size mismatch for output_head.geo_map.weight"):
+        complete_state_dict(bad)
+
+
+def test_visualize_page_matches_the_reference_contract():
+    """visualize_page (reference detectors/_east/utils.py:95-220): keyword-only style parameters with the reference's defaults,
+    RGB PIL image of the page's size; quads drawn in `color` on a page darkened by dark_alpha outside the (blurred) quad mask and
+    untouched deep inside it; show_order adds green centre-to-centre lines and a numbered black box per word; an empty page returns
+    the input."""
+    import inspect
+    from PIL import Image
+    from manuscript_ocr_amd import visualize_page
+    from manuscript_ocr_amd.detectors._types import Block, Page, Word
+    sig = inspect.signature(visualize_page)
+    assert [(n, p.default) for n, p in list(sig.parameters.items())[2:]] == [
+        ("show_order", False), ("color", (0, 0, 255)), ("thickness", 2), ("dark_alpha", 0.3), ("blur_ksize", 11),
+        ("line_color", (0, 255, 0)), ("number_color", (255, 255, 255)), ("number_bg", (0, 0, 0))]
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in list(sig.parameters.values())[2:])
+    img = np.full((120, 300, 3), 200, dtype=np.uint8)
+    page = Page(blocks=[Block(words=[Word(polygon=[[20.6, 20.2], [120.9, 20.0], [120.0, 80.0], [20.0, 80.0]], detection_confidence=0.9),
+                                     Word(polygon=[[160.0, 30.0], [280.0, 30.0], [280.0, 90.0], [160.0, 90.0]], detection_confidence=0.8)])])
+    out = visualize_page(img, page)
+    assert isinstance(out, Image.Image) and out.mode == "RGB" and out.size == (300, 120)
+    a = np.array(out)
+    assert tuple(a[50, 70]) == (200, 200, 200)            # deep inside a quad: untouched
+    assert tuple(a[110, 140]) == (140, 140, 140)          # far outside: img * (1 - 0.3), truncated to u8
+    assert tuple(a[20, 70]) == (0, 0, 255) and tuple(a[50, 20]) == (0, 0, 255)   # outline, vertex coordinates truncated to int
+    assert 140 < a[50, 123, 0] < 200                       # the blurred edge of the mask between the two quads
+    assert np.array_equal(np.array(visualize_page(Image.fromarray(img), page)), a)
+    o = np.array(visualize_page(img, page, show_order=True, color=(255, 0, 0), thickness=3))
+    c1 = ((20.6 + 120.9 + 120.0 + 20.0) / 4, (20.2 + 20.0 + 80.0 + 80.0) / 4)
+    assert tuple(o[int(c1[1]) + 10, int(c1[0]) + 10]) == (0, 0, 0)              # number box 24 x 24 around the centre
+    assert tuple(o[55, 150]) == (0, 255, 0)                                      # the line between the two centres
+    assert o[40:60, 60:80].max() > 128 and (o[40:60, 60:80] == 0).all(axis=2).mean() > 0.5   # light digits on the black box
+    empty = Page(blocks=[Block(words=[])])
+    pil = Image.fromarray(img)
+    assert visualize_page(pil, empty) is pil and np.array_equal(np.array(visualize_page(img, empty)), img)
