@@ -168,6 +168,44 @@ def live_pmc_traffic(a):
                         "workload (4 steps each), convolution-stage kernels only", "measured_in_this_run": True}, "ok"
 
 
+def timed_region(run_steps, steps, warmup, sync, dist, device):
+    """The bench contract's timing protocol, separated from the workload so that the N > 1 control flow can be exercised without a
+    GPU (tests/test_host_cpu.py::test_bench_timed_region_world2_gloo): two untimed priming steps, W warm-up steps, then EXACTLY K
+    steps bracketed by synchronize + barrier on both sides; the elapsed time is the MAX over ranks (one all_reduce of a double).
+    `sync` = torch.cuda.synchronize on the GPU; `dist` = torch.distributed or None; `device` = where the reduced scalar lives.
+    Returns (output of the last timed step, seconds)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # Setup, untimed and independent of --warmup: two priming steps (both alternating stream sets, allocator pools, lazily
+    # loaded code objects) followed by the same synchronize + barrier sequence that brackets the timed region, so that
+    # whatever the runtime or RCCL initialise on first use is initialised before the W warm-up steps even when W = 0.
+    run_steps(2)
+    sync()
+    barrier()
+    if warmup:
+        run_steps(warmup)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    out = run_steps(steps)
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return out, dt
+
+
+def emit(rank, res, fd):
+    """ONE JSON line, from rank 0 only, on the real stdout (fd)."""
+    if rank == 0:
+        os.write(fd, (json.dumps(res) + "\n").encode())
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -330,29 +368,7 @@ def main():
                 ph.append(("collect", t_, time.perf_counter(), dict(pipe.last_profile)))
         return out_
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # Setup, untimed and independent of --warmup: two priming steps (both alternating stream sets, allocator pools, lazily
-    # loaded code objects) followed by the same synchronize + barrier sequence that brackets the timed region, so that
-    # whatever the runtime or RCCL initialise on first use is initialised before the W warm-up steps even when W = 0.
-    run_steps(2)
-    torch.cuda.synchronize()
-    barrier()
-    out = None
-    out = run_steps(a.warmup) if a.warmup else None
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    out = run_steps(a.steps)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    out, dt = timed_region(run_steps, a.steps, a.warmup, torch.cuda.synchronize, dist, "cuda")
     # the path's one real exchange: decoded strings/boxes of every rank gathered (RCCL when world > 1)
     records = gather_records([r for i, p in enumerate(out) for r in page_records(rank * NP + i, p)], torch.device("cuda", local))
 
@@ -572,7 +588,7 @@ def main():
                   + (f"  {rec_[3]}" if len(rec_) > 3 else ""), file=sys.stderr)
     if rank == 0:
         print(f"[bench] steps_executed {executed_steps[0]}", file=sys.stderr)  # read by live_pmc_traffic of a parent run
-        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    emit(rank, res, real_stdout)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -122,20 +122,6 @@ int msocr_conv3x3_winograd42_fused(const msocr_conv_desc* d, const void* in, con
 int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, const float* u_weight, const void* workspace, const float* bias,
                                        const void* residual, void* out, void* stream);
 
-/* The same convolution in the ROW-SPLIT Winograd form (csrc/winograd_rs.hip): the transforms are split by axis around a GEMM whose
- * workgroups own the 4 points of one transform row, so the arrays streamed through HBM are Q = (B^T d) (2x the input) and
- * R = (M A) (2x the output) instead of V and Mw (4x each): 10 units of traffic per layer instead of 18.  Same u_weight as
- * msocr_conv3x3_winograd; Cout % 128 == 0, Cin % 16 == 0; results differ from the plain form by the rounding order of the
- * output transform only.  workspace: msocr_conv3x3_winograd_rs_workspace_bytes(d) bytes (-1 = shape not supported).  The three
- * stages are also callable one by one (rows_in -> gemm -> rows_out on one stream with the same workspace). */
-int64_t msocr_conv3x3_winograd_rs_workspace_bytes(const msocr_conv_desc* d);
-int msocr_conv3x3_winograd_rs(const msocr_conv_desc* d, const void* in, const float* u_weight, const float* bias,
-                              const void* residual, void* out, void* workspace, void* stream);
-int msocr_winograd_rs_rows_in(const msocr_conv_desc* d, const void* in, void* workspace, void* stream);
-int msocr_winograd_rs_gemm(const msocr_conv_desc* d, const float* u_weight, void* workspace, void* stream);
-int msocr_winograd_rs_rows_out(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual, void* out,
-                               void* stream);
-
 /* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->cpad (4 or 8) inside a zero canvas
  * out[N][Hp][Wp][cpad], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.
  *   mode 0: EAST ToTensor+Normalize, detectors/_east/infer.py:127-132,305  -> (x/255 - .5)/.5

@@ -61,11 +61,6 @@ _SIGS = {
     "msocr_conv3x3_winograd42_fused_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd42_fused": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_fused_gemm_output": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "msocr_conv3x3_winograd_rs_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
-    "msocr_conv3x3_winograd_rs": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "msocr_winograd_rs_rows_in": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
-    "msocr_winograd_rs_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
-    "msocr_winograd_rs_rows_out": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),

@@ -27,13 +27,9 @@ __device__ __attribute__((aligned(16))) uint32_t msocr_zero16[4] = {0u, 0u, 0u, 
 // LEAN: 1x1 kernel without padding (every 1x1 convolution and the batched GEMMs of the Winograd path) — a K-tile is a plain
 // pointer increment, no tap decoding, no bounds masks (rows >= M load valid garbage that the epilogue never stores).  PMC on
 // the Winograd GEMM counted 1.9 VALU + 1.2 SALU instructions per MFMA in the general loader; they share the SIMD's issue port.
-// WPE: workgroups per CU the register allocation is held to (0 = 3 for the one-stage 128-byte-row form, else 2); STAG: stagger
-// the start of every third workgroup of a CU's share by part of a K-tile so that co-resident workgroups do not run their
-// barrier / staging phases in lockstep (diagnostic variants, MSOCR_GEMM_VARIANT).
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0,
-          bool DIRECT = false>
+// WPE: workgroups per CU the register allocation is held to (0 = 3 for the one-stage 128-byte-row form, else 2).
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0>
 __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 : 2)) void conv_igemm_kernel(ConvParams p) {
-  static_assert(!DIRECT || (MT == 16 && sizeof(T) == 4), "direct epilogue: f32 16x16x4 tiles");
   constexpr int ES = sizeof(T);
   constexpr int CPR = BKB / 16;  // 16-B chunks per tile row
   constexpr int EPC = 16 / ES;   // elements per chunk
@@ -165,10 +161,6 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
 
   const int r32 = lane & (MT - 1), half = lane / MT;
 
-  if constexpr (STAG != 0) {  // blocks b, b + 256, b + 512 tend to share a CU: delay them by 0 / 1 / 2 thirds of a K-tile's MFMA time
-    const int ph = (blockIdx.x >> 8) % 3;
-    for (int q = 0; q < ph * STAG; ++q) __builtin_amdgcn_s_sleep(127);
-  }
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -204,10 +196,7 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              if constexpr (DIRECT)  // transposed tile: the lane's 4 accumulators are 4 consecutive output channels of one row
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[j][e]), __uint_as_float(fa[i][e]), acc[i][j], 0, 0, 0);
-              else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i][e]), __uint_as_float(fb[j][e]), acc[i][j], 0, 0, 0);
       }
     } else {
     u32x4 fa[2][TM], fb[2][TN];
@@ -245,25 +234,6 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
     __syncthreads();
   }
 
-  if constexpr (DIRECT) {
-    // ---- direct epilogue: no LDS round trip, no barriers.  acc[i][j] = D[n = 4 * half + e][m = r32] of the (i, j) 16x16 tile, so a
-    // lane stores 16 bytes (4 consecutive output channels) of row m; the TN tiles of a wave fill 64 contiguous bytes per row each ----
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long m = (long)tile_m * BM + wm * WM + i * MT + r32;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int co = tile_n * BN + wn * WN + j * MT + 4 * half;
-        f32x4 v = acc[i][j];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-        if (p.has_res) v += *reinterpret_cast<const f32x4*>(p.res + (m * p.res_ld + co) * ES);
-        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        *reinterpret_cast<f32x4*>(g_out + (m * p.out_ld + co) * ES) = v;
-      }
-    }
-    return;
-  }
   // ---- epilogue: TM passes of (acc row-block -> LDS [PR][BN] f32 -> bias/residual/ReLU -> 16-B stores) ----
   constexpr int PR = (BM / WM) * 32;  // tile rows handled per pass
   float* sc = reinterpret_cast<float*>(smem);
@@ -329,8 +299,7 @@ __global__ __launch_bounds__(256, WPE ? WPE : ((STAGES == 1 && BKB <= 128) ? 3 :
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0, int STAG = 0,
-          bool DIRECT = false>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int STAGES = 2, bool LEAN = false, int MT = 32, int WPE = 0>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
@@ -338,9 +307,9 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
   p.cin_tiles = p.Cin / BK;
   p.ktiles = p.KH * p.KW * p.cin_tiles;
   constexpr int STAGE = (BM + BN) * BKB;
-  constexpr int EPI = DIRECT ? 0 : (BM / WM) * 32 * BN * 4;
+  constexpr int EPI = (BM / WM) * 32 * BN * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT, WPE, STAG, DIRECT>;
+  auto kern = conv_igemm_kernel<T, BM, BN, BKB, WM, WN, STAGES, LEAN, MT, WPE>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -358,41 +327,21 @@ static int launch_typed(ConvParams& p, hipStream_t s) {
   constexpr int ES = sizeof(T);
   // row bytes: 128 B when Cin allows (f32: BK 32, bf16: BK 64), else 64 B
   const bool wide = (p.Cin * ES) % 128 == 0;
-  // variant 1 (default for f32): ONE LDS stage, 3 workgroups per CU — a third resident workgroup covers the other two's
-  // prologue/epilogue, worth 3-5 % on the short-K (Winograd, 1x1) launches; variant 0: register-staged double buffer, 2/CU.
-  static const int variant = getenv("MSOCR_CONV_VARIANT") ? atoi(getenv("MSOCR_CONV_VARIANT")) : (sizeof(T) == 4 ? 1 : 0);
+  // The f32 instances keep ONE LDS stage at 3-4 workgroups per CU (a resident neighbour covers the others' prologue / epilogue: worth
+  // 3-5 % at short K); bf16 keeps the register-staged double buffer at 2 per CU.  `lean` = 1x1 kernel without padding.
+  const bool lean = p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0;
   if (p.Cout % 128 == 0) {
     if constexpr (sizeof(T) == 4) {
-      static const int lean_on = getenv("MSOCR_CONV_LEAN") ? atoi(getenv("MSOCR_CONV_LEAN")) : 1;
-      // MT16: v_mfma_f32_16x16x4_f32 tiles (same FLOP per cycle, half the accumulator traffic per FLOP, fragments read just in
-      // time): +1-4 % on the lean GEMM launches; 2 = also the general 3x3 loader (diagnostic)
-      static const int mt16 = getenv("MSOCR_CONV_MT16") ? atoi(getenv("MSOCR_CONV_MT16")) : 1;
-      if (wide && variant == 1 && mt16 == 2 && !(lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0))
-        return launch_cfg<T, 128, 128, 128, 64, 64, 1, false, 16>(p, s);
-      if (wide && variant == 1 && lean_on && mt16 && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0) {
-        // default 2: K-tiles of 16 (64-byte rows), 128 VGPRs, FOUR workgroups per CU: +1-2 % on the short-K launches in isolation
-        // (tools/gemm_probe.py) and +2.3 % on the pipeline (49.3 against 48.2 pages/s, three A/B pairs); 0 = K-tiles of 32 at 3 per CU
-        const int gv = getenv("MSOCR_GEMM_VARIANT") ? atoi(getenv("MSOCR_GEMM_VARIANT")) : 2;
-        if (gv == 1 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1, true, 16, 2>(p, s);  // BK = 64, 2 per CU
-        if (gv == 2) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);                              // BK = 16, 4 per CU
-        if (gv == 3) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 3, 8>(p, s);                          // staggered start
-        if (gv == 4) return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16, 4>(p, s);                             // 4 per CU (128 VGPRs)
-        if (gv == 5) return launch_cfg<T, 128, 128, 128, 64, 64, 2, true, 16, 2>(p, s);                             // two LDS stages, 2 per CU
-        if (gv == 6) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4, 0, true>(p, s);                     // as 2, direct epilogue
-        if (gv == 7 && p.Ktot <= 256) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4, 0, true>(p, s);    // direct epilogue at short K only
-        if (gv == 7) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);
-        return launch_cfg<T, 128, 128, 128, 64, 64, 1, true, 16>(p, s);
-      }
-      if (wide && variant == 1 && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0)
-        return launch_cfg<T, 128, 128, 128, 64, 64, 1, true>(p, s);
+      // lean: v_mfma_f32_16x16x4_f32 tiles, K-tiles of 16 (64-byte rows), 128 VGPRs, FOUR workgroups per CU (round 2: +2.3 % on the
+      // pipeline against K-tiles of 32 at 3 per CU; K-tiles of 64, staggered workgroup starts, two LDS stages and a direct-store
+      // epilogue all measured within 1 % of these two and are gone)
+      if (wide && lean) return launch_cfg<T, 128, 128, 64, 64, 64, 1, true, 16, 4>(p, s);
+      if (wide) return launch_cfg<T, 128, 128, 128, 64, 64, 1>(p, s);
     }
-    if (wide && variant == 1) return launch_cfg<T, 128, 128, 128, 64, 64, 1>(p, s);
-    if (variant == 2 && (p.Cin * ES) % 256 == 0) return launch_cfg<T, 128, 128, 256, 64, 64, 1>(p, s);
     return wide ? launch_cfg<T, 128, 128, 128, 64, 64>(p, s) : launch_cfg<T, 128, 128, 64, 64, 64>(p, s);
   } else if (p.Cout % 64 == 0) {
     if constexpr (sizeof(T) == 4) {
-      static const int lean_on = getenv("MSOCR_CONV_LEAN") ? atoi(getenv("MSOCR_CONV_LEAN")) : 1;
-      if (wide && lean_on && p.KH == 1 && p.KW == 1 && p.PH == 0 && p.PW == 0) return launch_cfg<T, 128, 64, 128, 64, 32, 2, true>(p, s);
+      if (wide && lean) return launch_cfg<T, 128, 64, 128, 64, 32, 2, true>(p, s);
     }
     return wide ? launch_cfg<T, 128, 64, 128, 64, 32>(p, s) : launch_cfg<T, 128, 64, 64, 64, 32>(p, s);
   } else {

@@ -91,14 +91,6 @@ def _wino_workspace(nbytes, device):
     return buf
 
 
-# Row-split Winograd form (csrc/winograd_rs.hip: half the transform traffic, a 4-point GEMM at 2 workgroups per CU).  Measured
-# per layer (tools/conv_bench.py): Cin = 256 layers 6-9 % faster than the plain form, Cin = 512 layers 2 % slower (the GEMM's lower
-# occupancy costs more than the transforms save).  In the pipeline (three A/B pairs, 16 pages per step): off 48.5 / Cin <= 256 48.2 /
-# every layer 45.9 pages/s, with 655 / 587 / ~445 GB of HBM traffic per step — so it is OFF by default and kept as the low-traffic
-# option: 0 = off (default), 1 = layers with Cin <= 256, 2 = every supported layer.
-WINOGRAD_ROW_SPLIT = int(os.environ.get("MSOCR_WINO_RS", "0"))
-
-
 # Tall Winograd form F(4,3) x F(2,3) (csrc/winograd.hip, wino42_*): 24 transform points per 4x2 outputs = 3 multiplies per output
 # instead of 4, V / Mw 3x instead of 4x.  Taken when it is cheaper for the map height: 24 * ceil(H/4) < 16 * ceil(H/2)
 # (H = 4, 7, 8, 11, 12, >= 15 ...).  MSOCR_WINO_TALL=0 keeps every layer on F(2x2,3x3).
@@ -261,7 +253,6 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
     if use_wino:
         L = nat.lib()
         tall = bool(WINOGRAD_TALL) and _tall_pays(H) and getattr(w, "_msocr_wino42", None) is not None
-        rs = (not tall) and Cout % 128 == 0 and (WINOGRAD_ROW_SPLIT >= 2 or (WINOGRAD_ROW_SPLIT == 1 and Cin <= 256))
         if tall:
             u = w._msocr_wino42
             name, f_ws, whole = "winograd42", L.msocr_conv3x3_winograd42_workspace_bytes, L.msocr_conv3x3_winograd42
@@ -270,10 +261,6 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
             if up is not None and SPLIT_BF16X3:  # the 24 GEMMs on the bf16 pipes with exactly split operands
                 u, name, whole, st_gemm = up, "winograd42_split", L.msocr_conv3x3_winograd42_split, L.msocr_winograd42_gemm_split
             TH, TW, npts = (Ho + 3) // 4, (Wo + 1) // 2, 24
-        elif rs:
-            name, f_ws, whole = "winograd_rs", L.msocr_conv3x3_winograd_rs_workspace_bytes, L.msocr_conv3x3_winograd_rs
-            st_in, st_gemm, st_out = L.msocr_winograd_rs_rows_in, L.msocr_winograd_rs_gemm, L.msocr_winograd_rs_rows_out
-            TH, TW, npts = (Ho + 1) // 2, (Wo + 1) // 2, 16
         else:
             name, f_ws, whole = "winograd", L.msocr_conv3x3_winograd_workspace_bytes, L.msocr_conv3x3_winograd
             st_in, st_gemm, st_out = L.msocr_winograd_input_transform, L.msocr_winograd_gemm, L.msocr_winograd_output_transform
@@ -293,8 +280,8 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
                 nat.check(whole(ctypes.byref(d), xp, u.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
             else:  # the same three kernels through the per-stage entry points, one event pair each
                 nn, mt = n1 - n0, (n1 - n0) * TH * TW
-                v_el = 4 * nn * TH * (2 * TW + 2) * Cin if rs else npts * mt * Cin  # transformed input array (Q or V), elements
-                m_el = (8 if rs else npts) * mt * Cout                              # transformed output array (R or Mw)
+                v_el = npts * mt * Cin   # transformed input array V, elements
+                m_el = npts * mt * Cout  # transformed output array Mw
                 e = _prof_begin()
                 nat.check(st_in(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
                 _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + v_el), (mt, Cin))

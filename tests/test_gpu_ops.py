@@ -83,16 +83,16 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
-@pytest.mark.parametrize("form", ["tall", "rs", "plain"])
+@pytest.mark.parametrize("form", ["tall", "plain"])
 def test_conv3x3_winograd_vs_direct_and_f64(ops, case, form, monkeypatch):
     """Winograd paths (ops.attach_winograd + conv2d dispatch) against an f64 convolution: same 2e-5 bound as the direct kernel, and
     the error stays within a small multiple of the direct kernel's own error against f64 (rounding order only).
     tall: F(4,3) x F(2,3) (csrc/winograd.hip wino42_*; forced on every height here, so H = 1, 7, 17 exercise its partial tiles;
-    its 6-point H transform is allowed 8x the direct error, measured ~2-4x); rs: the axis-split F(2x2) form on every layer it supports
-    (csrc/winograd_rs.hip, Cout % 128 == 0); plain: the V / Mw F(2x2) form (csrc/winograd.hip)."""
+    its 6-point H transform is allowed 8x the direct error, measured ~2-4x); plain: the V / Mw F(2x2) form (csrc/winograd.hip).
+    Both with the exact-f32 GEMM (the split-operand GEMM of the tall form: test_winograd42_split_vs_exact_and_f64)."""
     monkeypatch.setattr(ops, "WINOGRAD_TALL", 1 if form == "tall" else 0)
     monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
-    monkeypatch.setattr(ops, "WINOGRAD_ROW_SPLIT", 2 if form == "rs" else 0)
+    monkeypatch.setattr(ops, "SPLIT_BF16X3", 0)
     err_mult = 8 if form == "tall" else 4
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]))

@@ -510,3 +510,64 @@ def test_visualize_page_matches_the_reference_contract():
     empty = Page(blocks=[Block(words=[])])
     pil = Image.fromarray(img)
     assert visualize_page(pil, empty) is pil and np.array_equal(np.array(visualize_page(img, empty)), img)
+
+
+BENCH_WORKER = r'''
+import importlib.util, json, os, sys, time
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.environ["REPO"], "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+from manuscript_ocr_amd.dist import gather_records, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+log = []
+def run_steps(k):                      # the workload stub: rank 1 is the slow rank
+    log.append(("run", k))
+    time.sleep(0.05 * k * (1 + 3 * rank))
+    return [f"rank{rank}-page{i}" for i in range(2)]
+class D:                               # torch.distributed with the calls recorded, so that their order can be asserted
+    ReduceOp = dist.ReduceOp
+    @staticmethod
+    def barrier():
+        log.append(("barrier",)); dist.barrier()
+    @staticmethod
+    def all_reduce(t, op=None):
+        log.append(("all_reduce", str(op))); dist.all_reduce(t, op=op)
+out, dt = bench.timed_region(run_steps, 3, 1, lambda: log.append(("sync",)), D, "cpu")
+recs = gather_records([{"page": rank * 2 + i, "text": o} for i, o in enumerate(out)], torch.device("cpu"))
+lo, hi = shard_range(7, rank, world)
+r, w = os.pipe()
+bench.emit(rank, {"value": 2 * 3 * world / dt, "n_gpus": world}, w)
+os.close(w)
+line = os.read(r, 4096).decode()
+print("RESULT" + json.dumps({"rank": rank, "dt": dt, "log": log, "recs": recs, "shard": [lo, hi], "line": line}))
+dist.destroy_process_group()
+'''
+
+
+def test_bench_timed_region_world2_gloo(tmp_path):
+    """bench.py's own N > 1 control flow with 2 CPU ranks over gloo and the workload stubbed (VERDICT r2 #10): the order
+    prime -> sync -> barrier -> warm-up -> sync -> barrier -> EXACTLY K timed steps -> sync -> barrier -> all_reduce(MAX);
+    both ranks end with the SAME elapsed time and it is the slow rank's; the records of both ranks reach rank 0 in page order;
+    only rank 0 writes the JSON line; shards are contiguous and cover all pages."""
+    import json
+    script = tmp_path / "bw.py"
+    script.write_text(BENCH_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-600:] for o in outs]
+    res = [json.loads([l for l in o[0].splitlines() if l.startswith("RESULT")][0][len("RESULT"):]) for o in outs]
+    res.sort(key=lambda r: r["rank"])
+    expected = [["run", 2], ["sync"], ["barrier"], ["run", 1], ["sync"], ["barrier"], ["run", 3], ["sync"], ["barrier"],
+                ["all_reduce", "RedOpType.MAX"]]
+    for r in res:
+        assert r["log"] == expected, r["log"]
+    assert res[0]["dt"] == res[1]["dt"] and res[0]["dt"] >= 0.05 * 3 * 4 * 0.95  # the slow rank's 0.6 s, on both
+    assert [x["page"] for x in res[0]["recs"]] == [0, 1, 2, 3] and res[0]["recs"][3]["text"] == "rank1-page1"
+    assert json.loads(res[0]["line"])["n_gpus"] == 2 and res[1]["line"] == ""
+    assert res[0]["shard"] == [0, 4] and res[1]["shard"] == [4, 7]
