@@ -99,12 +99,16 @@ int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* work
  *   (in_sH == W * in_sW, in_sN == H * in_sH), Cin % 32 == 0, Cout % 64 == 0; weight_planes = [3][Cout][Cin] bf16 on the device.
  *   Same flags, epilogue and reference layers as msocr_conv2d (torchvision Bottleneck conv1 / conv3 / downsample, DecoderBlock
  *   conv1x1, SEBasicBlock downsample, the BiLSTM input projections and linears).
+ * msocr_conv2d_split: msocr_conv2d for MSOCR_F32 with any kernel size / stride / padding (the strided 3x3 and 1x1 convolutions of
+ *   the two ResNet trunks, which have no Winograd form), weight_planes = [3][Cout][KH][KW][Cin] bf16; Cin % 32 == 0, Cout % 64 == 0.
  * msocr_winograd42_gemm_split / msocr_conv3x3_winograd42_split: stage 2 of / the whole msocr_conv3x3_winograd42 with
  *   u_planes = [3][24][Cout][Cin] bf16 = msocr_split_bf16x3_host of msocr_winograd42_weights_host's output (Cin % 32, Cout % 64).
  * Results differ from the exact-f32 entry points by rounding only (tests/test_gpu_ops.py bounds both against an f64 reference). */
 int msocr_split_bf16x3_host(const float* w_host, int64_t n, uint16_t* planes_out_host);
 int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
                         const void* residual, void* out, void* stream);
+int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
+                       const void* residual, void* out, void* stream);
 int msocr_winograd42_gemm_split(const msocr_conv_desc* d, const void* u_planes, void* workspace, void* stream);
 int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
                                    const void* residual, void* out, void* workspace, void* stream);

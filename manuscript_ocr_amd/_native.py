@@ -56,6 +56,7 @@ _SIGS = {
     "msocr_winograd42_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_split_bf16x3_host": (c_i32, [c_vp, c_i64, c_vp]),
     "msocr_conv1x1_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv2d_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_gemm_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd42_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd42_fused_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -39,8 +39,14 @@ __device__ __forceinline__ uint32_t split_step(float& x, float& y) {
   return pk;
 }
 
-// BN in {128, 64}; wave tile 64 x WN (WN = BN / 2); K-tile = 32 elements (A rows 128 B of f32 in HBM, 64 B per bf16 plane in LDS)
-template <int BN, int WPE>
+// 16 zero bytes: padded (out-of-image) taps of the general loader read from here
+__device__ __attribute__((aligned(16))) uint32_t msocr_split_zero16[4] = {0u, 0u, 0u, 0u};
+
+// BN in {128, 64}; wave tile 64 x WN (WN = BN / 2); K-tile = 32 elements (A rows 128 B of f32 in HBM, 64 B per bf16 plane in LDS).
+// GEN = false: 1x1 / stride 1 / no padding over a dense pixel sequence and the batched GEMMs — a K-tile is a plain pointer
+// increment.  GEN = true: any kernel size / stride / padding (the implicit-GEMM loader of conv_igemm.hip: a K-tile lies inside one
+// filter tap because Cin % 32 == 0; out-of-image taps read zeros).
+template <int BN, int WPE, bool GEN>
 __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   constexpr int BM = 128, WM = 64, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -77,13 +83,25 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   // ---- staging coordinates ----
   const int a_chunk = tid & 7, a_row0 = tid >> 3;
   const char* a_ptr[A_IT];
+  int a_hi0[A_IT], a_wi0[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     long m = (long)tile_m * BM + a_row0 + i * 32;
     if (m >= p.M) m = p.M - 1;  // rows past the end: valid addresses, values never stored
-    // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements)
-    a_ptr[i] = g_in + (m * p.sW + a_chunk * 4) * 4;
+    if constexpr (GEN) {
+      const long hw = (long)p.Ho * p.Wo;
+      const int n = (int)(m / hw);
+      const int rem = (int)(m - (long)n * hw);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.SH - p.PH;
+      a_wi0[i] = wo * p.SW - p.PW;
+      a_ptr[i] = g_in + ((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_chunk * 4) * 4;
+    } else {
+      // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements)
+      a_ptr[i] = g_in + (m * p.sW + a_chunk * 4) * 4;
+    }
   }
+  int t_kh = 0, t_kw = 0, t_c0 = 0;  // GEN: tap and channel offset of the NEXT K-tile load_tile() will fetch
   const int b_chunk = tid & 3, b_row0 = tid >> 2;
   const char* b_ptr[B_IT];
 #pragma unroll
@@ -95,8 +113,23 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
 
   u32x4 ra[A_IT], rb[3][B_IT];
   auto load_tile = [&](int kt) {
+    if constexpr (GEN) {
+      const long koff = ((long)t_kh * p.sH + (long)t_kw * p.sW + t_c0) * 4;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (long)kt * 128);
+      for (int i = 0; i < A_IT; ++i) {
+        const int hi = a_hi0[i] + t_kh, wi = a_wi0[i] + t_kw;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        ra[i] = *reinterpret_cast<const u32x4*>(ok ? a_ptr[i] + koff : reinterpret_cast<const char*>(msocr_split_zero16));
+      }
+      t_c0 += 32;
+      if (t_c0 == p.Cin) {
+        t_c0 = 0;
+        if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (long)kt * 128);
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -209,7 +242,7 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   }
 }
 
-template <int BN, int WPE>
+template <int BN, int WPE, bool GEN>
 int launch_split(ConvParams& p, hipStream_t s) {
   p.tilesM = (int)((p.M + 127) / 128);
   p.tilesN = p.Cout / BN;
@@ -217,7 +250,7 @@ int launch_split(ConvParams& p, hipStream_t s) {
   constexpr int STAGE = 3 * (128 + BN) * 64;
   constexpr int EPI = 64 * BN * 4;
   constexpr int LDS = STAGE > EPI ? STAGE : EPI;
-  auto kern = conv_split_kernel<BN, WPE>;
+  auto kern = conv_split_kernel<BN, WPE, GEN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -230,10 +263,9 @@ int launch_split(ConvParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 
-int launch_split_any(ConvParams& p, hipStream_t s) {
-  static const int wpe = getenv("MSOCR_SPLIT_WPE") ? atoi(getenv("MSOCR_SPLIT_WPE")) : 3;
-  if (p.Cout % 128 == 0) return wpe == 2 ? launch_split<128, 2>(p, s) : launch_split<128, 3>(p, s);
-  return wpe == 2 ? launch_split<64, 2>(p, s) : launch_split<64, 3>(p, s);
+int launch_split_any(ConvParams& p, hipStream_t s, bool general) {
+  if (general) return p.Cout % 128 == 0 ? launch_split<128, 3, true>(p, s) : launch_split<64, 3, true>(p, s);
+  return p.Cout % 128 == 0 ? launch_split<128, 3, false>(p, s) : launch_split<64, 3, false>(p, s);
 }
 
 }  // namespace
@@ -290,7 +322,39 @@ extern "C" int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, con
   p.has_res = has_res ? 1 : 0;
   p.nbatch = 1; p.bsA = p.bsW = p.bsO = 0;
   p.wplane = (long)d->Cout * d->Cin;
-  return launch_split_any(p, (hipStream_t)stream);
+  return launch_split_any(p, (hipStream_t)stream, false);
+}
+
+// Any kernel size / stride / padding with the weight operand as three bf16 planes [3][Cout][KH][KW][Cin] (the strided 3x3 and 1x1
+// convolutions of the ResNet trunks that have no Winograd form).  Same descriptor rules as msocr_conv2d for MSOCR_F32, plus
+// Cin % 32 == 0 and Cout % 64 == 0.
+extern "C" int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
+                                  const void* residual, void* out, void* stream) {
+  if (!d || !in || !weight_planes || !out || d->dtype != MSOCR_F32) return MSOCR_E_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0) return MSOCR_E_ARG;
+  if (d->Cin <= 0 || d->Cin % 32 || d->Cout <= 0 || d->Cout % 64) return MSOCR_E_ARG;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0) return MSOCR_E_ARG;
+  if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;  // 16-byte vector accesses
+  if (((uintptr_t)in | (uintptr_t)weight_planes | (uintptr_t)out) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  // output extent must agree with the conv arithmetic (guards the kernel's indexing)
+  if ((d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 < d->Ho || (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1 < d->Wo)
+    return MSOCR_E_ARG;
+  ConvParams p = {};
+  p.in = (const char*)in; p.w = (const char*)weight_planes; p.bias = bias; p.res = (const char*)residual; p.out = (char*)out;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.sN = d->in_sN; p.sH = d->in_sH; p.sW = d->in_sW;
+  p.KH = d->KH; p.KW = d->KW; p.SH = d->stride_h; p.SW = d->stride_w; p.PH = d->pad_h; p.PW = d->pad_w;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.M = (long)d->N * d->Ho * d->Wo;
+  p.Ktot = (long)d->KH * d->KW * d->Cin;
+  p.out_ld = d->out_ld; p.res_ld = d->res_ld;
+  p.relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
+  p.has_res = has_res ? 1 : 0;
+  p.nbatch = 1; p.bsA = p.bsW = p.bsO = 0;
+  p.wplane = (long)d->Cout * p.Ktot;
+  return launch_split_any(p, (hipStream_t)stream, true);
 }
 
 // nbatch independent GEMMs of one shape in ONE launch, C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]: A f32 [nbatch][M][K],
@@ -310,5 +374,5 @@ int msocr_internal_gemm_split_batched(const float* A, const uint16_t* Bplanes, f
   p.relu = 0; p.has_res = 0;
   p.nbatch = nbatch; p.bsA = M * (long)K; p.bsW = (long)N * K; p.bsO = M * (long)N;
   p.wplane = (long)nbatch * N * K;
-  return launch_split_any(p, s);
+  return launch_split_any(p, s, false);
 }

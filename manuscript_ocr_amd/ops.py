@@ -122,11 +122,26 @@ def split_planes(t):
     return planes.view(torch.bfloat16).to(t.device)
 
 
-def attach_split(w, split=None):
-    """Load-time: give a [Cout,1,1,Cin] f32 device weight its three bf16 planes; conv2d() then takes msocr_conv1x1_split for
-    1x1 / stride 1 / no padding calls on pixel-dense inputs."""
+# Below this reduction length (KH * KW * Cin) a convolution stays on the exact-f32 kernel: measured on the MI355X (round 3,
+# profiles/r03_conv_layers_split_all.txt) the split kernel's K-tiles of 32 with two barriers each lose to the exact lean kernel's
+# K-tiles of 16 at K = 64 (55 against 64 TFLOP/s) and K = 128 (83 against 91), and win from K = 256 up.
+SPLIT_MIN_K = int(os.environ.get("MSOCR_SPLIT_MIN_K", "256"))
+
+
+def _split_eligible(w):
     Cout, KH, KW, Cin = w.shape
-    if (SPLIT_BF16X3 if split is None else split) and w.dtype == torch.float32 and KH == 1 and KW == 1 and Cin % 32 == 0 and Cout % 64 == 0:
+    return w.dtype == torch.float32 and Cin % 32 == 0 and Cout % 64 == 0 and KH * KW * Cin >= SPLIT_MIN_K
+
+
+def attach_split(w, split=None):
+    """Load-time: give a [Cout,1,1,Cin] f32 device weight its three bf16 planes (conv2d() then takes the split-operand kernels);
+    split=False marks the weight as exact-f32 only (precision="fp32-exact").  Weights of other kernel sizes get their planes on
+    first use as a strided / non-Winograd convolution (conv2d), so a 3x3 weight that only ever runs as Winograd holds none."""
+    if split is False:
+        w._msocr_nosplit = True
+        return w
+    Cout, KH, KW, Cin = w.shape
+    if (SPLIT_BF16X3 if split is None else split) and KH == 1 and KW == 1 and _split_eligible(w):
         w._msocr_split = split_planes(w)
     return w
 
@@ -294,12 +309,17 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
         d.N = N
     else:
         wp = getattr(w, "_msocr_split", None)
-        split = (wp is not None and SPLIT_BF16X3 and (KH, KW, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and (Ho, Wo) == (H, W)
-                 and x.stride(1) == W * x.stride(2) and (N == 1 or x.stride(0) == H * W * x.stride(2)))
+        if (wp is None and SPLIT_BF16X3 and not getattr(w, "_msocr_nosplit", False) and _split_eligible(w)
+                and not torch.cuda.is_current_stream_capturing()):
+            wp = w._msocr_split = split_planes(w)  # first use of this weight outside the Winograd path: split once, keep
+        split = wp is not None and SPLIT_BF16X3 and KH * KW * Cin >= SPLIT_MIN_K and all(v % 4 == 0 for v in x.stride()[:3])
+        lean = (split and (KH, KW, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and (Ho, Wo) == (H, W)
+                and (H == 1 or x.stride(1) == W * x.stride(2)) and (N == 1 or x.stride(0) == H * W * x.stride(2)))
         e = _prof_begin()
         if split:
-            rc = nat.lib().msocr_conv1x1_split(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), bp, rp, out.data_ptr(), _stream())
-            nat.check(rc, f"msocr_conv1x1_split {tuple(x.shape)} * {tuple(w.shape)}")
+            fn = nat.lib().msocr_conv1x1_split if lean else nat.lib().msocr_conv2d_split
+            rc = fn(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), bp, rp, out.data_ptr(), _stream())
+            nat.check(rc, f"msocr_conv{'1x1' if lean else '2d'}_split {tuple(x.shape)} * {tuple(w.shape)}")
         else:
             rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
             nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")

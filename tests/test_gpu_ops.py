@@ -40,12 +40,19 @@ CONV_CASES = [
     (3, 4, 13, 512, 512, (2, 2), (2, 1), (0, 1), True, False),
     (1, 9, 11, 2048, 512, (1, 1), (1, 1), (0, 0), True, False),
     (1, 33, 47, 32, 64, (3, 3), (1, 1), (1, 1), False, False),
+    (2, 16, 50, 128, 256, (3, 3), (2, 2), (1, 1), True, False),   # TRBA layer1.0.conv1: 3x3 / 2
+    (2, 8, 25, 256, 512, (1, 1), (2, 2), (0, 0), False, True),    # a strided downsample with a residual
 ]
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol,split", [(torch.float32, 2e-5, 0), (torch.float32, 2e-5, 1), (torch.bfloat16, 2e-2, 0)])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_vs_torch(ops, case, dtype, tol):
+def test_conv2d_vs_torch(ops, case, dtype, tol, split, monkeypatch):
+    """split = 0: the exact-f32 (or bf16) implicit-GEMM kernel; split = 1: every eligible f32 case (Cin % 32 == 0, Cout % 64 == 0)
+    through the split-operand kernels — msocr_conv1x1_split for dense 1x1 / stride 1, msocr_conv2d_split (general loader: taps,
+    stride, padding) for the rest — with the K threshold lifted so that short reductions are covered too."""
+    monkeypatch.setattr(ops, "SPLIT_BF16X3", split)
+    monkeypatch.setattr(ops, "SPLIT_MIN_K", 0)
     N, H, W, Cin, Cout, k, stride, pad, relu, use_res = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -62,8 +69,12 @@ def test_conv2d_vs_torch(ops, case, dtype, tol):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
+    ops.PROFILE = []
     out = ops.conv2d(_to_nhwc(x, dtype), _w_khwc(w, dtype), b.cuda(), stride, pad, relu,
                      _to_nhwc(res, dtype) if use_res else None)
+    tag = ops.PROFILE[0][4][3]
+    ops.PROFILE = None
+    assert tag == ("direct_split" if (split and Cin % 32 == 0 and Cout % 64 == 0) else "direct"), tag
     torch.cuda.synchronize()
     got = out.float().cpu().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
@@ -106,7 +117,7 @@ def test_conv3x3_winograd_vs_direct_and_f64(ops, case, form, monkeypatch):
     if relu:
         ref = F.relu(ref)
     xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
-    w_direct = _w_khwc(w, torch.float32)
+    w_direct = ops.attach_split(_w_khwc(w, torch.float32), False)  # the exact-f32 direct kernel
     w_wino = ops.attach_winograd(_w_khwc(w, torch.float32))
     assert getattr(w_wino, "_msocr_wino", None) is not None and not hasattr(w_direct, "_msocr_wino")
     out_d = ops.conv2d(xd, w_direct, b.cuda(), (1, 1), (1, 1), relu, rd)
@@ -131,10 +142,11 @@ SPLIT_1X1_CASES = [
 
 
 @pytest.mark.parametrize("case", SPLIT_1X1_CASES)
-def test_conv1x1_split_vs_exact_and_f64(ops, case):
+def test_conv1x1_split_vs_exact_and_f64(ops, case, monkeypatch):
     """Split-operand 1x1 convolution (csrc/conv_split.hip: each f32 operand = three bf16 terms, six products on the bf16 matrix
     pipes, f32 accumulate) against an f64 product: the same 2e-5 bound as the exact-f32 kernel and within 2x of that kernel's own
     error (+ 1e-6) — i.e. the three dropped cross terms (<= 2^-25 of a product) do not show."""
+    monkeypatch.setattr(ops, "SPLIT_MIN_K", 0)
     (N, H, W), Cin, Cout, relu, use_res, extra = case
     g = torch.Generator().manual_seed(Cin + Cout + H)
     xw = torch.randn(N, H, W, Cin + extra, generator=g)
@@ -149,7 +161,7 @@ def test_conv1x1_split_vs_exact_and_f64(ops, case):
         ref = torch.relu(ref)
     xd = xw.cuda()[..., extra:]
     rd = res.cuda() if use_res else None
-    w_e = w.cuda()
+    w_e = ops.attach_split(w.cuda(), False)   # exact-f32 only
     w_s = ops.attach_split(w.cuda(), True)
     assert w_s._msocr_split.shape == (3, Cout, 1, 1, Cin) and w_s._msocr_split.dtype == torch.bfloat16
     assert torch.equal(w_s._msocr_split.float().sum(0).cpu(), w)  # the planes add up to the weight exactly
@@ -236,7 +248,7 @@ def test_conv3x3_fused64_winograd_vs_direct_and_f64(ops, case):
     if pool:
         ref = F.max_pool2d(ref, 2, 2)
     xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
-    w_direct = _w_khwc(w, torch.float32)
+    w_direct = ops.attach_split(_w_khwc(w, torch.float32), False)  # the exact-f32 direct kernel
     w_f = ops.attach_winograd(_w_khwc(w, torch.float32))
     assert getattr(w_f, "_msocr_wino42_fused", None) is not None and getattr(w_f, "_msocr_wino", None) is None
     out_d = ops.conv2d(xd, w_direct, b.cuda(), (1, 1), (1, 1), relu, rd)
