@@ -48,16 +48,19 @@ __device__ __attribute__((aligned(16))) uint32_t msocr_split_zero16[4] = {0u, 0u
 // filter tap because Cin % 32 == 0; out-of-image taps read zeros).
 template <int BN, int WPE, bool GEN>
 __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
-  constexpr int BM = 128, WM = 64, WN = BN / 2;
+  constexpr int BM = 128, WM = 64, WN = BN / 2, BK = 32;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int ROWB = 64;                 // bytes per LDS plane row (32 bf16)
+  constexpr int ROWB = BK * 2;             // bytes per LDS plane row (BK bf16)
   constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
-  constexpr int A_IT = BM / 32;            // A: 8 x 16-B chunks per f32 row, 32 rows per pass of 256 threads
-  constexpr int B_IT = BN / 64;            // B: 4 x 16-B chunks per bf16 row, 64 rows per pass; per plane
+  constexpr int STAGE_B = 3 * (A_PLANE + B_PLANE);
+  constexpr int ACH = BK / 4;              // A: 16-B chunks per f32 row
+  constexpr int ARP = 256 / ACH;           //    rows per pass of 256 threads
+  constexpr int A_IT = BM / ARP;
+  constexpr int BCH = BK / 8;              // B: 16-B chunks per bf16 row
+  constexpr int BRP = 256 / BCH;
+  constexpr int B_IT = (BN + BRP - 1) / BRP;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const sA = smem;                 // [3][BM][64 B]
-  unsigned char* const sB = smem + 3 * A_PLANE;   // [3][BN][64 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -81,12 +84,16 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   char* const g_out = p.out + (long)batch * p.bsO * 4;
 
   // ---- staging coordinates ----
-  const int a_chunk = tid & 7, a_row0 = tid >> 3;
-  const char* a_ptr[A_IT];
-  int a_hi0[A_IT], a_wi0[A_IT];
+  // Lean form: every address is a wave-uniform base (SGPRs: batch + K-tile + plane) plus a 32-bit per-thread offset (one VGPR per
+  // load), so the loop holds 4 + B_IT address registers instead of ten 64-bit pointers — the 168-register budget of 3 workgroups per
+  // CU then leaves no spill in the loop (a spilled, freshly loaded register made every K-tile wait for a memory round trip).
+  const int a_chunk = tid % ACH, a_row0 = tid / ACH;
+  const char* a_ptr[GEN ? A_IT : 1];
+  uint32_t a_off[GEN ? 1 : A_IT];
+  int a_hi0[GEN ? A_IT : 1], a_wi0[GEN ? A_IT : 1];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    long m = (long)tile_m * BM + a_row0 + i * 32;
+    long m = (long)tile_m * BM + a_row0 + i * ARP;
     if (m >= p.M) m = p.M - 1;  // rows past the end: valid addresses, values never stored
     if constexpr (GEN) {
       const long hw = (long)p.Ho * p.Wo;
@@ -97,17 +104,18 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
       a_wi0[i] = wo * p.SW - p.PW;
       a_ptr[i] = g_in + ((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_chunk * 4) * 4;
     } else {
-      // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements)
-      a_ptr[i] = g_in + (m * p.sW + a_chunk * 4) * 4;
+      // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements); < 4 GB (host check)
+      a_off[i] = (uint32_t)((m * p.sW + a_chunk * 4) * 4);
     }
   }
   int t_kh = 0, t_kw = 0, t_c0 = 0;  // GEN: tap and channel offset of the NEXT K-tile load_tile() will fetch
-  const int b_chunk = tid & 3, b_row0 = tid >> 2;
-  const char* b_ptr[B_IT];
+  const int b_chunk = tid % BCH, b_row0 = tid / BCH;
+  uint32_t b_off[B_IT];
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
-    const int co = tile_n * BN + b_row0 + j * 64;
-    b_ptr[j] = g_w + ((long)co * p.Ktot + b_chunk * 8) * 2;
+    int co = tile_n * BN + b_row0 + j * BRP;
+    if (co >= p.Cout) co = p.Cout - 1;
+    b_off[j] = (uint32_t)(((long)co * p.Ktot + b_chunk * 8) * 2);
   }
   const long wplane_b = p.wplane * 2;
 
@@ -121,24 +129,30 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
         const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         ra[i] = *reinterpret_cast<const u32x4*>(ok ? a_ptr[i] + koff : reinterpret_cast<const char*>(msocr_split_zero16));
       }
-      t_c0 += 32;
+      t_c0 += BK;
       if (t_c0 == p.Cin) {
         t_c0 = 0;
         if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
       }
     } else {
+      const char* const ga = g_in + (long)kt * (BK * 4);  // uniform
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (long)kt * 128);
+      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ga + a_off[i]);
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) {
+      const char* const gb = g_w + pl * wplane_b + (long)kt * (BK * 2);  // uniform
 #pragma unroll
-      for (int j = 0; j < B_IT; ++j) rb[pl][j] = *reinterpret_cast<const u32x4*>(b_ptr[j] + pl * wplane_b + (long)kt * 64);
+      for (int j = 0; j < B_IT; ++j)
+        if (BN % BRP == 0 || b_row0 + j * BRP < BN) rb[pl][j] = *reinterpret_cast<const u32x4*>(gb + b_off[j]);
+    }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    unsigned char* const sA = smem + stage * STAGE_B;  // [3][BM][ROWB] (one stage: stage == 0)
+    unsigned char* const sB = sA + 3 * A_PLANE;        // [3][BN][ROWB]
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int row = a_row0 + i * 32;
+      const int row = a_row0 + i * ARP;
       float x0 = __uint_as_float(ra[i][0]), x1 = __uint_as_float(ra[i][1]), x2 = __uint_as_float(ra[i][2]), x3 = __uint_as_float(ra[i][3]);
       // this thread's 4 elements are bf16 positions 4 * a_chunk .. + 3 of the row: half of 16-B chunk a_chunk / 2
       unsigned char* dst = sA + row * ROWB + (((a_chunk >> 1) ^ swz<ROWB>(row)) << 4) + ((a_chunk & 1) << 3);
@@ -154,8 +168,9 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int j = 0; j < B_IT; ++j) {
-        const int row = b_row0 + j * 64;
-        *reinterpret_cast<u32x4*>(sB + pl * B_PLANE + row * ROWB + ((b_chunk ^ swz<ROWB>(row)) << 4)) = rb[pl][j];
+        const int row = b_row0 + j * BRP;
+        if (BN % BRP == 0 || row < BN)
+          *reinterpret_cast<u32x4*>(sB + pl * B_PLANE + row * ROWB + ((b_chunk ^ swz<ROWB>(row)) << 4)) = rb[pl][j];
       }
   };
 
@@ -169,14 +184,11 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
 
   const int r32 = lane & 31, half = lane >> 5;
 
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-
-  for (int kt = 0; kt < p.ktiles; ++kt) {
-    if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
+  auto compute = [&](int stage) {
+    const unsigned char* const sA = smem + stage * STAGE_B;
+    const unsigned char* const sB = sA + 3 * A_PLANE;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {              // two k16 steps per K-tile
+    for (int q = 0; q < BK / 16; ++q) {        // k16 steps per K-tile
       const int c = 2 * q + half;
       bf16x8 fa[3][TM], fb[3][TN];
 #pragma unroll
@@ -204,8 +216,22 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();  // one LDS stage: everyone is done reading before it is overwritten
-    if (kt + 1 < p.ktiles) store_tile();
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // One LDS stage, two barriers per K-tile, 3 workgroups per CU.  Measured alternatives (round 3, gpurun_out/r3_split_variants.txt,
+  // f32-equivalent TFLOP/s at K = 512 / 4096 on M = 161280, N = 512): this loop 156 / 182; two LDS stages with K-tiles of 16 (one
+  // barrier per tile, 3 per CU) 145 / 148; two stages with K-tiles of 32 (1 per CU) 120 / 148; K-tiles of 16 at 4 per CU 126 / 94;
+  // 2 per CU 154 / 176.  Timing ablations of this loop: MFMAs + fragment reads alone 266, + restaging 228, + loads that always hit
+  // the cache 190.
+  for (int kt = 0; kt < p.ktiles; ++kt) {
+    if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
+    compute(0);
+    __syncthreads();  // everyone is done reading the stage before it is overwritten
+    if (kt + 1 < p.ktiles) store_tile(0);
     __syncthreads();
   }
 
@@ -264,6 +290,8 @@ int launch_split(ConvParams& p, hipStream_t s) {
 }
 
 int launch_split_any(ConvParams& p, hipStream_t s, bool general) {
+  // the lean loader addresses with 32-bit byte offsets from a uniform base: operands of 4 GB or more take the general loader (64-bit)
+  if (!general && ((p.M * p.sW + 32) * 4 >= (1L << 32) || ((long)p.Cout * p.Ktot + 32) * 2 >= (1L << 32))) general = true;
   if (general) return p.Cout % 128 == 0 ? launch_split<128, 3, true>(p, s) : launch_split<64, 3, true>(p, s);
   return p.Cout % 128 == 0 ? launch_split<128, 3, false>(p, s) : launch_split<64, 3, false>(p, s);
 }
