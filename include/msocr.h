@@ -239,6 +239,14 @@ int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_
                     int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
                     int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
                     const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
+/* msocr_attn_beam with the context half of the LSTMCell input product hoisted out of the step loop (matrix-core kernel only):
+ * ctx_gates [B][T][H][4] f32 = batch_H x rnn.weight_ih[:, :H]^T with the four gates of a unit adjacent (row j*4+g of the
+ * product), computed once per call by a GEMM (msocr_conv1x1_split).  W_ih[:, :H] (sum_t alpha_t batch_H_t) == sum_t alpha_t
+ * (W_ih[:, :H] batch_H_t): same result up to f32 summation order, half the matrix work per step. */
+int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B,
+                            int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
+                            int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
+                            const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
 int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                              float* logits_out, int32_t* ids_out, void* stream);
 

@@ -30,6 +30,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Per-phase timestamps of workgroup 0 (dev builds only: tools/attn_phase_times.sh compiles this file with -DMSOCR_ATTN_TIMING)
+#ifdef MSOCR_ATTN_TIMING
+__device__ unsigned long long msocr_attn_timing[64 * 16];
+extern "C" int msocr_attn_timing_read(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(msocr_attn_timing), sizeof(msocr_attn_timing)) == hipSuccess ? 0 : -2;
+}
+#define TSTAMP(ph) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) msocr_attn_timing[s * 16 + (ph)] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(ph) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int H = 256;        // hidden size (ATT_H)
@@ -129,7 +140,14 @@ __device__ __forceinline__ void mfma_gates(const float* __restrict__ sX, int k0,
   }
 }
 
-__global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
+// HOIST: the context half of the LSTMCell input product is hoisted out of the step loop.  The reference computes
+// gates = W_ih [ctx ; onehot] + W_hh h with ctx = sum_t alpha_t batch_H_t (model.py:40-45); since W_ih[:, :H] ctx =
+// sum_t alpha_t (W_ih[:, :H] batch_H_t), the products P_t = W_ih[:, :H] batch_H_t are computed ONCE per crop by a GEMM before the
+// kernel (a.ctx_gates, [B][T][H][4]) and a step only forms sum_t alpha_t P_t on the VALU (13 x 1024 FMAs per row instead of
+// 256 x 1024 MACs): half of the step's matrix work, 1 of its 2.5 MB of weights and the ctx phase (d) disappear.  Same arithmetic
+// up to the order of the f32 summation.
+template <bool HOIST>
+__global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sX = lds;                 // [R][XS]   ctx (0..255) | h (256..511)
   float* sbuf = sX + R * XS;       // [R][H]    ph, then logits, then scratch of the state permutation
@@ -157,6 +175,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
   const float temp = fmaxf(a.temperature, 1e-6f);
 
   for (int s = 0; s < a.steps; ++s) {
+    TSTAMP(0);
     // ---- (a) ph[r][j] = h2h_b[j] + sum_k h[r][k] * h2h_wt[k][j]
     {
       f32x16 acc;
@@ -168,6 +187,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = acc[e];
     }
     __syncthreads();
+    TSTAMP(1);
     // ---- (b) e[r][t] = sum_j score_w[j] * tanh(proj_H[crop][t][j] + ph[r][j]) : one wave per (crop, t) group — the
     //      proj_H row is read once for the crop's 8 beams; the rows of up to GB groups are in flight together
     {
@@ -217,6 +237,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+    TSTAMP(2);
     // ---- (c) softmax over t
     if (tid < R) {
       float m = -INFINITY;
@@ -230,8 +251,9 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       for (int t = 0; t < T; ++t) salpha[tid * 64 + t] = salpha[tid * 64 + t] / sum;
     }
     __syncthreads();
+    TSTAMP(3);
     // ---- (d) ctx[r][j] = sum_t alpha[r][t] * batch_H[crop(r)][t][j] : thread = (j, half of the crops)
-    {
+    if constexpr (!HOIST) {
       const int j = tid & 255, ch = tid >> 8;
 #pragma unroll
       for (int n2 = 0; n2 < NB / 2; ++n2) {
@@ -256,7 +278,8 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
         for (int q = 0; q < KB8; ++q) sX[(nb * KB8 + q) * XS + j] = accd[q];
       }
     }
-    __syncthreads();
+    if constexpr (!HOIST) __syncthreads();
+    TSTAMP(4);
     // ---- (e) gates + LSTM cell for units ju, rows acc_row(e, half)
     {
       f32x16 acc[4];
@@ -268,7 +291,32 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g][e] = b4[g] + t4[g];
       }
-      mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+      if constexpr (HOIST) {
+        // + sum_t alpha[row][t] * P[crop(row)][t][ju][gate]; this lane's rows of crop nb are beams 4 * half + 0..3 = acc elements 4 nb + i
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float* pP = a.ctx_gates + ((long)min(b0 + nb, a.B - 1) * T * H + ju) * 4;
+          const float* pa = salpha + (nb * KB8 + 4 * half) * 64;
+          for (int t0 = 0; t0 < T; t0 += 8) {  // 8 loads in flight, then the FMAs
+            f32x4 pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (t0 + u < T) pv[u] = *reinterpret_cast<const f32x4*>(pP + (long)(t0 + u) * H * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (t0 + u < T) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float al = pa[i * 64 + t0 + u];
+#pragma unroll
+                  for (int g = 0; g < 4; ++g) acc[g][4 * nb + i] = fmaf(al, pv[u][g], acc[g][4 * nb + i]);
+                }
+              }
+          }
+        }
+      } else {
+        mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+      }
       mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
       __syncthreads();  // every wave has read the old h
 #pragma unroll
@@ -279,6 +327,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+    TSTAMP(5);
     // ---- (f) logits[r][v] = gen_b[v] + sum_k h'[r][k] * gen_wt[k][v]; temperature; trace store
     {
       const bool vok = ju < V;
@@ -300,6 +349,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+    TSTAMP(6);
     // ---- (g) log-sum-exp per row: wave w handles rows 4w..4w+3
     for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
       float m = -INFINITY;
@@ -312,6 +362,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       if (lane == 0) s_lse[r] = m + logf(sum);
     }
     __syncthreads();
+    TSTAMP(7);
     // ---- (h) top-K of the K*V candidates of every crop: ONE wave per crop (lane owns v = lane + 64 i), the K rounds of
     //      arg-max + winner removal need no workgroup barrier.  Order: larger value, then smaller flat index beam*V + v.
     const float lp = a.lp ? a.lp[s] : 1.0f;
@@ -368,6 +419,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+    TSTAMP(8);
     // ---- (i) bookkeeping per state row
     int nd = 1;
     if (tid < R) {
@@ -407,6 +459,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
         }
       }
     }
+    TSTAMP(9);
     // ---- (j) permute beam state by src within every crop: c through sbuf (logits are consumed), h through registers
     {
 #pragma unroll
@@ -430,6 +483,7 @@ __global__ __launch_bounds__(NT, 2) void attn_beam_mfma_kernel(AttnArgs a) {
       for (int q = 0; q < R / 2; ++q) sX[(ch * (R / 2) + q) * XS + H + j] = hn[q];
     }
     __syncthreads();
+    TSTAMP(10);
     // ---- early exit (model.py:215 breaks the loop once every beam of every row of the chunk is finished): leave after
     //      step s when every chunk this workgroup's crops belong to has all its crops finished at steps <= s + 1, i.e. the
     //      chunk's run length T_run = max finish step is covered.  Nobody waits: a workgroup that cannot see the others'
@@ -461,10 +515,14 @@ int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s) {
   const size_t ldsz = (size_t)(R * XS + R * H + R * 64) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_beam_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
-  MSOCR_LAUNCH(attn_beam_mfma_kernel, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
+  if (a.ctx_gates)
+    MSOCR_LAUNCH(attn_beam_mfma_kernel<true>, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
+  else
+    MSOCR_LAUNCH(attn_beam_mfma_kernel<false>, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }

@@ -18,6 +18,7 @@ __attribute__((visibility("hidden"))) int msocr_internal_gemm_split_batched(cons
 struct AttnArgs {
   const float* batch_H;
   const float* proj_H;
+  const float* ctx_gates;  // optional (matrix-core beam kernel): [B][T][H][4] = batch_H x rnn.weight_ih[:, :H]^T, hoisted out of the step loop
   msocr_attn_weights w;
   int B, T, V, steps, K;
   int sos_id, eos_id, blank_id;

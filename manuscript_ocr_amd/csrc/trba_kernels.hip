@@ -698,14 +698,36 @@ extern "C" int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, i
   return beam_ws_logits(B, steps, beam, V) + (int64_t)B * steps * beam * 8 + (int64_t)B * steps * 4 + 256;
 }
 
+static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B, int T, int H,
+                          int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
+                          int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
+                          int32_t* chunk_state_dev, void* stream);
+
 extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_weights* w, int B, int T, int H, int V,
                                int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
                                int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
                                int32_t* chunk_state_dev, void* stream) {
+  return attn_beam_impl(batch_H, proj_H, nullptr, w, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id, fin_step_out,
+                        workspace, chunk_id_dev, chunk_size_dev, chunk_state_dev, stream);
+}
+
+extern "C" int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                                       int B, int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id,
+                                       int eos_id, int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
+                                       const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream) {
+  if (!ctx_gates || ((uintptr_t)ctx_gates & 15)) return MSOCR_E_ARG;
+  return attn_beam_impl(batch_H, proj_H, ctx_gates, w, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id, fin_step_out,
+                        workspace, chunk_id_dev, chunk_size_dev, chunk_state_dev, stream);
+}
+
+static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B, int T, int H,
+                          int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
+                          int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
+                          int32_t* chunk_state_dev, void* stream) {
   if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !fin_step_out || !workspace) return MSOCR_E_ARG;
   if (beam < 1 || beam > ATT_KMAX || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
   AttnArgs a{};
-  a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w;
+  a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w; a.ctx_gates = ctx_gates;
   a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = beam;
   a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = temperature; a.lp = lp_dev;
   char* p = (char*)workspace;
@@ -727,6 +749,7 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
   const char* em = getenv("MSOCR_BEAM_MFMA");  // read per call: tests switch kernels inside one process
   const bool use_mfma = !(em && em[0] == '0');
   if (use_mfma && HB == 1) return msocr_internal_attn_beam_mfma(a, (hipStream_t)stream);
+  a.ctx_gates = nullptr;  // the VALU kernels form the context vector themselves
   const size_t lds = (size_t)2 * HB * T * ATT_H * sizeof(float);
   static bool attr = false;
   if (!attr) {

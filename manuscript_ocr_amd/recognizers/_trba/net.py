@@ -15,6 +15,8 @@ The CNN may run in bf16 (`dtype`); recurrent and attention stages are always exa
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from ... import _native as nat
@@ -36,6 +38,10 @@ def _gate_interleave(w_t, H):
     K = w_t.shape[0]
     return w_t.reshape(K, 4, H).permute(0, 2, 1).contiguous()
 
+
+# Beam decode: hoist the context half of the LSTMCell input product out of the step loop (csrc/attn_beam_mfma.hip, HOIST);
+# MSOCR_BEAM_HOIST=0 keeps the reference's per-step formulation.
+HOIST_CTX = os.environ.get("MSOCR_BEAM_HOIST", "1") != "0"
 
 LAYER_SPEC = (("layer1", 1, 2), ("layer2", 2, 1), ("layer3", 5, 2), ("layer4", 3, 1))
 
@@ -103,6 +109,10 @@ class TrbaNet:
             "gen_wt": sd["attn.generator.weight"].float().t().contiguous().to(dev),
             "gen_b": sd["attn.generator.bias"].float().contiguous().to(dev),
         }
+        # rows of rnn.weight_ih[:, :H] reordered unit-major (row j*4+g): the hoisted context product of the beam kernel
+        # (msocr_attn_beam_hoisted) is one GEMM batch_H x this^T -> [B*T, H*4]
+        self.att["wih_ctx_rows"] = ops.attach_split(w_ih[:, :H].reshape(4, H, H).permute(1, 0, 2).reshape(4 * H, 1, 1, H).contiguous().to(dev),
+                                                    split)
         aw = nat.AttnWeights()
         for k in ("h2h_wt", "h2h_b", "score_w", "wih_ctx_t", "wih_tok", "whh_t", "b_gates", "gen_wt", "gen_b"):
             setattr(aw, k, self.att[k].data_ptr())
@@ -184,13 +194,19 @@ class TrbaNet:
                                                    dtype=torch.float32).to(self.device)
                 torch.cuda.synchronize()
             lp = self._lp_cache[key]
+        hoist = HOIST_CTX and os.environ.get("MSOCR_BEAM_MFMA", "1") != "0"
+        if hoist:  # W_ih[:, :H] batch_H_t for every frame, once per call instead of W_ih[:, :H] ctx in every step
+            ctxg = self._gemm(batch_H.reshape(B * T, H), self.att["wih_ctx_rows"], None)
         e = ops._prof_begin()
-        nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
-                                            beam_size, lp.data_ptr() if lp is not None else None, float(temperature), sos_id, eos_id,
-                                            -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(),
-                                            chunks[0].data_ptr() if chunks else None, chunks[1].data_ptr() if chunks else None,
-                                            chunks[2].data_ptr() if chunks else None, ops._stream()),
-                  "attn_beam")
+        tail = (B, T, H, self.V, steps, beam_size, lp.data_ptr() if lp is not None else None, float(temperature), sos_id, eos_id,
+                -1 if blank_id is None else blank_id, fin.data_ptr(), ws.data_ptr(),
+                chunks[0].data_ptr() if chunks else None, chunks[1].data_ptr() if chunks else None,
+                chunks[2].data_ptr() if chunks else None, ops._stream())
+        if hoist:
+            nat.check(nat.lib().msocr_attn_beam_hoisted(batch_H.data_ptr(), proj_H.data_ptr(), ctxg.data_ptr(), ctypes.byref(self._aw), *tail),
+                      "attn_beam_hoisted")
+        else:
+            nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), *tail), "attn_beam")
         # SURVEY.md 8d, per decode step: proj_H + batch_H (shared by the beams) + LSTMCell W_ih (ctx part + one-hot rows), W_hh,
         # generator, h2h + per row (h, c state + logits); the launch runs up to `steps` of them (chunk-level early exit)
         V, R = self.V, B * beam_size

@@ -135,10 +135,26 @@ def calibrated_logit_bounds(trba_net, ref_batch_H, dev_batch_H, exp_rows, mode, 
         pert = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=ref_batch_H + noise)
         pooled.append(row_logit_errors(pert, exp_rows))
     pooled = np.concatenate(pooled)
-    on_dev = row_logit_errors(oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=dev_batch_H), exp_rows)
+    rows_on_dev = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=dev_batch_H)
+    on_dev = row_logit_errors(rows_on_dev, exp_rows)
     factor = 2.0
     return {"oracle_noise": pooled, "oracle_on_dev_H": on_dev, "factor": factor,
+            # the ORACLE's decoder run on the DEVICE's encoder output: the reference decode of what the device decoder was given
+            "rows_on_dev_H": rows_on_dev,
             "enc_err_rel": float(np.abs(delta).max() / max(1e-30, np.abs(ref_batch_H).max())),
             "enc_rms_rel": float(np.sqrt((delta ** 2).mean()) / max(1e-30, np.sqrt((ref_batch_H ** 2).mean()))),
             "p50": factor * float(np.quantile(pooled, 0.5)), "p90": factor * float(np.quantile(pooled, 0.9)),
             "max": factor * float(pooled.max())}
+
+
+def admit_encoder_sensitive(rep_e2e, rep_dec):
+    """End-to-end differences that are NOT near-ties of the oracle's decode (rep_e2e["hard"]) are admitted only when they are
+    explained by the encoder's in-tolerance f32 error ALONE: the row must be identical, ids and run length, to the ORACLE's own
+    decoder started from the DEVICE's encoder output (rep_dec = compare_decodes(device, oracle_decode_chunks(batch_H = device
+    batch_H))).  For such a row the device decoder reproduces the reference decoder exactly; the two encoder outputs differ within
+    the stated tolerance and the reference's decoder itself maps them to different strings.  Returns (still_hard, admitted)."""
+    same_dec = set(rep_dec["same"])
+    still, admitted = [], []
+    for h in rep_e2e["hard"]:
+        (admitted if h[0] in same_dec else still).append(h)
+    return still, admitted

@@ -64,4 +64,4 @@ def compare_texts(got_texts, exp, itos, eos_id=2, max_ties=1):
 
 
 # all-random-weights decode parity: the checker lives with the oracle (bench.py's cpu_baseline uses it too)
-from oracle.decode_check import calibrated_logit_bounds, compare_decodes, oracle_decode_chunks  # noqa: E402,F401
+from oracle.decode_check import admit_encoder_sensitive, calibrated_logit_bounds, compare_decodes, oracle_decode_chunks  # noqa: E402,F401

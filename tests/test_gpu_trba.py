@@ -161,15 +161,31 @@ def _random_weight_case(otm, seed, N, mode, rec, canv=None, max_len=25):
     return ids, trun, conf, lg, exp, cal
 
 
-def _assert_near_tie_parity(rep, N, what, cal):
-    """Zero differences that are not near-ties of the oracle's own decode; near-tie rows capped at 3 % (+1); the per-row logit
-    error within the calibrated bounds (median, 90th percentile and maximum <= 2x the oracle decoder's own response to an
-    encoder-output perturbation of the measured size)."""
-    msg = (f"{what}: {len(rep['same'])}/{N} rows identical, ties {rep['ties']}, run-length-only rows {rep['run_length_only']}, "
-           f"hard {rep['hard']}, max logit err {rep['max_logit_err_rel']:.2e} of max|logit|")
+def _assert_near_tie_parity(rep, N, what, cal, got=None, mode=None):
+    """(1) DECODER parity: the device's decode against the ORACLE's decoder started from the device's own encoder output
+    (cal["rows_on_dev_H"]): every row identical up to near-ties of that decode (margin < TIE_TOL), logits within 1e-4 of
+    max |logit| — both decoders see the same input, only the decoder's own f32 rounding differs.
+    (2) END TO END against the oracle's decode of ITS encoder output: zero differences that are neither near-ties of the oracle's
+    own decode nor rows explained by the encoder's in-tolerance error alone (identical to (1)'s reference; oracle/decode_check.py::
+    admit_encoder_sensitive); those two kinds together capped at 3 % (+1); the per-row logit error within the calibrated bounds
+    (median, 90th percentile and maximum <= 2x the oracle decoder's own response to an encoder-output perturbation of the
+    measured size)."""
+    from conftest import admit_encoder_sensitive, compare_decodes
+    admitted = []
+    if got is not None:
+        ids, trun, lg = got
+        rep_dec = compare_decodes(ids, trun, lg, cal["rows_on_dev_H"], mode, logit_rtol=DECODER_LOGIT_RTOL)
+        msg_d = (f"{what} [decoder only]: {len(rep_dec['same'])}/{N} rows identical to the oracle decoder on the device's batch_H, ties "
+                 f"{rep_dec['ties']}, hard {rep_dec['hard']}, max logit err {rep_dec['max_logit_err_rel']:.2e}")
+        print(msg_d)
+        assert not rep_dec["hard"] and len(rep_dec["ties"]) <= 1 + (3 * N) // 100, msg_d
+        rep["hard"], admitted = admit_encoder_sensitive(rep, rep_dec)
+    msg = (f"{what}: {len(rep['same'])}/{N} rows identical, ties {rep['ties']}, encoder-sensitive rows {admitted}, run-length-only rows "
+           f"{rep['run_length_only']}, hard {rep['hard']}, max logit err {rep['max_logit_err_rel']:.2e} of max|logit|")
     print(msg)
     assert not rep["hard"], msg
-    assert len(rep["ties"]) <= 1 + (3 * N) // 100, msg
+    assert len(rep["ties"]) + len(admitted) <= 1 + (3 * N) // 100, msg
+    rep["encoder_sensitive"] = admitted
     err = np.array(rep["row_logit_err_rel"])
     q = lambda v, p: float(np.quantile(v, p))
     print(f"{what}: encoder error {cal['enc_err_rel']:.2e} of max|batch_H| (rms {cal['enc_rms_rel']:.2e}); logit error / max|logit| "
@@ -186,6 +202,10 @@ RANDOM_WEIGHT_SEED = 20260128
 # difference of the SE-ResNet31 + 2 BiLSTMs (measured 2e-5 .. 6e-5 on these weights).  Everything downstream of it is bounded
 # by calibration (calibrated_logit_bounds), not by a chosen constant.
 ENCODER_ERR_REL = 2e-4
+# Decoder alone (device decode against the oracle's decoder started from the device's own batch_H): stated bound on the f32 rounding
+# difference of 25-41 chained attention / LSTM steps, relative to max |logit|: 2x the largest measured value (1.1e-5 .. 8.6e-5 over
+# the ten cases of this file, gpurun_out/r3_trba3.log; ids 256/256, 40/40, 96/96 identical with no ties).
+DECODER_LOGIT_RTOL = 2e-4
 
 
 @pytest.mark.parametrize("mode", ["greedy", "beam"])
@@ -208,7 +228,8 @@ def test_trba_random_weights_decode_parity(env, mode):
                config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda")
     ids, trun, conf, lg, exp, cal = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, mode, rec)
     rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=cal["max"])
-    _assert_near_tie_parity(rep, N, f"random weights / {mode}", cal)
+    _assert_near_tie_parity(rep, N, f"random weights / {mode}", cal, (ids, trun, lg), mode)
+    rep["chunks_with_ties"] |= {exp[h[0]]["chunk"] for h in rep["encoder_sensitive"]}
     assert len({tuple(e["ids"].tolist()) for e in exp}) > N // 2, "degenerate fixture: decodes do not vary"
     itos, _ = otm.load_charset(CHARSET)
     by_chunk = {}
@@ -246,7 +267,7 @@ def test_trba_random_weights_recorded_round1_case(env, mode):
     canv = np.stack([imgproc.resize_and_pad(c, 32, 100) for c in crops])
     ids, trun, conf, lg, exp, cal = _random_weight_case(otm, RANDOM_WEIGHT_SEED, 40, mode, rec, canv=canv)
     rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=cal["max"])
-    _assert_near_tie_parity(rep, 40, f"round-1 recorded case / {mode}", cal)
+    _assert_near_tie_parity(rep, 40, f"round-1 recorded case / {mode}", cal, (ids, trun, lg), mode)
 
 
 @pytest.mark.parametrize("mode", ["greedy", "beam"])
@@ -263,7 +284,7 @@ def test_trba_shipped_config_32x128_maxlen40(env, mode):
     ids, trun, conf, lg, exp, cal = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, mode, rec, canv=canv, max_len=40)
     assert ids.shape[1] == (41 if mode == "greedy" else 40)
     rep = compare_decodes(ids, trun, lg, exp, mode, logit_rtol=cal["max"])
-    _assert_near_tie_parity(rep, N, f"shipped config 32x128 / max_len 40 / {mode}", cal)
+    _assert_near_tie_parity(rep, N, f"shipped config 32x128 / max_len 40 / {mode}", cal, (ids, trun, lg), mode)
 
 
 def test_trba_random_weights_three_way(env, monkeypatch):
@@ -290,7 +311,7 @@ def test_trba_random_weights_three_way(env, monkeypatch):
     same = {}
     for name, (ids, trun, conf, lg, exp, cal) in results.items():
         rep = compare_decodes(ids, trun, lg, exp, "beam", logit_rtol=cal["max"])
-        _assert_near_tie_parity(rep, N, name, cal)
+        _assert_near_tie_parity(rep, N, name, cal, (ids, trun, lg), "beam")
         same[name] = set(rep["same"])
     names = list(results)
     for a in names:
