@@ -60,6 +60,56 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Wave-wide reductions on the DPP data path (quad_perm / row_half_mirror / row_mirror / row_bcast15 / row_bcast31: a few cycles per
+// step) instead of ds_bpermute shuffles (an LDS round trip per step): the decode step runs ~400 of them per wave.  The result is
+// complete in lane 63 (every lane of the last row for sums of full rows); *_bcast return it to all lanes through an SGPR.
+template <int CTRL, int RMASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, RMASK, 0xf, false));
+}
+template <int CTRL, int RMASK = 0xf>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RMASK, 0xf, false); }
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HMIRROR 0x141    // row_half_mirror: lane i <-> 7 - i inside each group of 8
+#define DPP_MIRROR 0x140     // row_mirror: lane i <-> 15 - i inside each row of 16
+#define DPP_BCAST15 0x142    // lane 15 of every row -> the next row (row_mask 0xA: rows 1 and 3 take it)
+#define DPP_BCAST31 0x143    // lane 31 -> rows 2 and 3 (row_mask 0xC)
+__device__ __forceinline__ float wave_sum63(float v) {  // total in lane 63
+  v += dpp_f<DPP_XOR1>(0.f, v);
+  v += dpp_f<DPP_XOR2>(0.f, v);
+  v += dpp_f<DPP_HMIRROR>(0.f, v);
+  v += dpp_f<DPP_MIRROR>(0.f, v);
+  v += dpp_f<DPP_BCAST15, 0xA>(0.f, v);
+  v += dpp_f<DPP_BCAST31, 0xC>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_max63(float v) {
+  v = fmaxf(v, dpp_f<DPP_XOR1>(v, v));
+  v = fmaxf(v, dpp_f<DPP_XOR2>(v, v));
+  v = fmaxf(v, dpp_f<DPP_HMIRROR>(v, v));
+  v = fmaxf(v, dpp_f<DPP_MIRROR>(v, v));
+  v = fmaxf(v, dpp_f<DPP_BCAST15, 0xA>(v, v));
+  v = fmaxf(v, dpp_f<DPP_BCAST31, 0xC>(v, v));
+  return v;
+}
+__device__ __forceinline__ float bcast63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+// arg-max with the beam search's tie rule (larger value first, then smaller flat index; NaN never wins): result in lane 63
+template <int CTRL, int RMASK = 0xf>
+__device__ __forceinline__ void argmax_step(float& v, int& i) {
+  const float ov = dpp_f<CTRL, RMASK>(v, v);
+  const int oi = dpp_i<CTRL, RMASK>(i, i);
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void wave_argmax63(float& v, int& i) {
+  argmax_step<DPP_XOR1>(v, i);
+  argmax_step<DPP_XOR2>(v, i);
+  argmax_step<DPP_HMIRROR>(v, i);
+  argmax_step<DPP_MIRROR>(v, i);
+  argmax_step<DPP_BCAST15, 0xA>(v, i);
+  argmax_step<DPP_BCAST31, 0xC>(v, i);
+}
+
 // row of accumulator register e in the 32x32 MFMA output layout (lane half = lane >> 5)
 __device__ __forceinline__ int acc_row(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
 
@@ -221,16 +271,12 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
 #pragma unroll
               for (int q = 0; q < H / 64; ++q) sacc[rb] = fmaf(sw[q], ftanh(pr[u][q] + sbuf[r * H + lane + 64 * q]), sacc[rb]);
             }
-            // 8 independent butterfly reductions, interleaved (the cross-lane latency of one hides behind the others)
+            // 8 independent wave sums on the DPP path, totals in lane 63
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
+            for (int rb = 0; rb < KB8; ++rb) sacc[rb] = wave_sum63(sacc[rb]);
+            if (lane == 63) {
 #pragma unroll
-              for (int rb = 0; rb < KB8; ++rb) sacc[rb] += __shfl_xor(sacc[rb], o);
-            if (lane < KB8) {
-              float v = sacc[0];
-#pragma unroll
-              for (int rb = 1; rb < KB8; ++rb) v = (lane == rb) ? sacc[rb] : v;
-              salpha[(nb * KB8 + lane) * 64 + t] = v;
+              for (int rb = 0; rb < KB8; ++rb) salpha[(nb * KB8 + rb) * 64 + t] = sacc[rb];
             }
           }
         }
@@ -238,17 +284,13 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
     }
     __syncthreads();
     TSTAMP(2);
-    // ---- (c) softmax over t
-    if (tid < R) {
-      float m = -INFINITY;
-      for (int t = 0; t < T; ++t) m = fmaxf(m, salpha[tid * 64 + t]);
-      float sum = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const float ev = expf(salpha[tid * 64 + t] - m);
-        salpha[tid * 64 + t] = ev;
-        sum += ev;
-      }
-      for (int t = 0; t < T; ++t) salpha[tid * 64 + t] = salpha[tid * 64 + t] / sum;
+    // ---- (c) softmax over t: wave w handles rows 4w..4w+3, lane = t (T <= 64)
+    for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
+      const float ev0 = lane < T ? salpha[r * 64 + lane] : -INFINITY;
+      const float m = bcast63(wave_max63(ev0));
+      const float ev = lane < T ? expf(ev0 - m) : 0.f;
+      const float sum = bcast63(wave_sum63(ev));
+      if (lane < T) salpha[r * 64 + lane] = ev / sum;
     }
     __syncthreads();
     TSTAMP(3);
@@ -354,12 +396,11 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
     for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
       float m = -INFINITY;
       for (int v = lane; v < V; v += 64) m = fmaxf(m, sbuf[r * H + v]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      m = bcast63(wave_max63(m));
       float sum = 0.f;
       for (int v = lane; v < V; v += 64) sum += expf(sbuf[r * H + v] - m);
-      sum = wave_sum(sum);
-      if (lane == 0) s_lse[r] = m + logf(sum);
+      sum = wave_sum63(sum);
+      if (lane == 63) s_lse[r] = m + logf(sum);  // libm-grade exp / log: the scores of a beam search are sums of these
     }
     __syncthreads();
     TSTAMP(7);
@@ -370,6 +411,14 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
       const int nb = wv;
       constexpr int VI = 4;  // V <= 256
       float cv[VI][KB8];
+      float lse_r[KB8], sc_r[KB8];
+      int dn_r[KB8];
+#pragma unroll
+      for (int rb = 0; rb < KB8; ++rb) {  // per-beam values once, not once per candidate
+        lse_r[rb] = s_lse[nb * KB8 + rb];
+        sc_r[rb] = s_score[nb * KB8 + rb];
+        dn_r[rb] = s_done[nb * KB8 + rb];
+      }
 #pragma unroll
       for (int i = 0; i < VI; ++i) {
         const int v = lane + 64 * i;
@@ -378,31 +427,45 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
           cv[i][rb] = -INFINITY;
           const int r = nb * KB8 + rb;
           if (v < V && rb < KB) {
-            float logp = sbuf[r * H + v] - s_lse[r];
-            if (s_done[r]) logp = (v == a.eos_id) ? 0.f : -INFINITY;
-            float tot = s_score[r] + logp;
+            float logp = sbuf[r * H + v] - lse_r[rb];
+            if (dn_r[rb]) logp = (v == a.eos_id) ? 0.f : -INFINITY;
+            float tot = sc_r[rb] + logp;
             if (a.lp) tot = tot / lp;
             cv[i][rb] = tot;
           }
         }
       }
-      for (int kk = 0; kk < KB; ++kk) {
-        float bvv = -INFINITY;
-        int bii = 0x7fffffff;
+      // per-lane cache: best candidate of every v-slot over the beams, and the lane's best over its slots.  A round then costs one
+      // wave arg-max + the rescan of the winner's slot (8 entries) instead of a scan of all 32 entries per lane.
+      float sv[VI], lv;
+      int sf[VI], lf;
+      auto rescan_slot = [&](int i) {
+        float bv = -INFINITY;
+        int bf = 0x7fffffff;
+        const int v = lane + 64 * i;
 #pragma unroll
-        for (int rb = 0; rb < KB8; ++rb)
-#pragma unroll
-          for (int i = 0; i < VI; ++i) {
-            const int v = lane + 64 * i, fi = rb * V + v;
-            const float x = cv[i][rb];
-            if (v < V && rb < KB && (x > bvv || (x == bvv && fi < bii))) { bvv = x; bii = fi; }
-          }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(bvv, o);
-          const int oi = __shfl_xor(bii, o);
-          if (ov > bvv || (ov == bvv && oi < bii)) { bvv = ov; bii = oi; }
+        for (int rb = 0; rb < KB8; ++rb) {
+          const float x = cv[i][rb];
+          const int fi = rb * V + v;
+          if (v < V && rb < KB && (x > bv || (x == bv && fi < bf))) { bv = x; bf = fi; }
         }
+        sv[i] = bv; sf[i] = bf;
+      };
+      auto rescan_lane = [&]() {
+        lv = sv[0]; lf = sf[0];
+#pragma unroll
+        for (int i = 1; i < VI; ++i)
+          if (sv[i] > lv || (sv[i] == lv && sf[i] < lf)) { lv = sv[i]; lf = sf[i]; }
+      };
+#pragma unroll
+      for (int i = 0; i < VI; ++i) rescan_slot(i);
+      rescan_lane();
+      for (int kk = 0; kk < KB; ++kk) {
+        float bvv = lv;
+        int bii = lf;
+        wave_argmax63(bvv, bii);
+        bvv = bcast63(bvv);
+        bii = __builtin_amdgcn_readlane(bii, 63);
         int wi_ = bii;
         if (wi_ == 0x7fffffff) wi_ = 0;  // every candidate NaN: degenerate input
         const int wr = wi_ / V, wc = wi_ - wr * V;
@@ -411,11 +474,18 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
           s_src[nb * KB8 + kk] = wr;
           s_nxt[nb * KB8 + kk] = wc;
         }
+        // the winner never wins again (NaN); wr, wc are wave-uniform, so is the slot wc >> 6: one slot is rescanned
+        const int wslot = wc >> 6;
+        const bool mine = (wc & 63) == lane;
 #pragma unroll
-        for (int rb = 0; rb < KB8; ++rb)
+        for (int i = 0; i < VI; ++i)
+          if (i == wslot) {
 #pragma unroll
-          for (int i = 0; i < VI; ++i)
-            if (rb == wr && lane + 64 * i == wc) cv[i][rb] = __int_as_float(0x7fc00000);  // the winner never wins again
+            for (int rb = 0; rb < KB8; ++rb)
+              if (mine && rb == wr) cv[i][rb] = __int_as_float(0x7fc00000);
+            rescan_slot(i);
+          }
+        rescan_lane();
       }
     }
     __syncthreads();
