@@ -184,9 +184,10 @@ extern "C" int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int
 // ds_read_b128 pair broadcasts the 8 row values of column k; W_hh^T rows stream from L2,
 // coalesced over j.  xproj already holds x W_ih^T + b_ih + b_hh.
 #define LSTM_RB 4
-__global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t, int B, int T,
-                                                      float* __restrict__ hcat) {
-  constexpr int H = 256, G = 4 * H, RB = LSTM_RB;
+template <int H>
+__global__ __launch_bounds__(H) void bilstm_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_t, int B, int T,
+                                                    float* __restrict__ hcat) {
+  constexpr int G = 4 * H, RB = LSTM_RB;
   __shared__ __attribute__((aligned(16))) float hs[2][H][RB];
   const int j = threadIdx.x, d = blockIdx.y;
   const int b0 = blockIdx.x * RB;
@@ -242,8 +243,18 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
 }
 
 extern "C" int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out, void* stream) {
-  if (!xproj || !w_hh_t || !hcat_out || B <= 0 || T <= 0 || H != 256) return MSOCR_E_ARG;
-  MSOCR_LAUNCH(bilstm_kernel, dim3((B + LSTM_RB - 1) / LSTM_RB, 2), dim3(256), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  if (!xproj || !w_hh_t || !hcat_out || B <= 0 || T <= 0) return MSOCR_E_ARG;
+  const dim3 grid((B + LSTM_RB - 1) / LSTM_RB, 2);
+  // hidden_size comes from the checkpoint's config (recognizers/_trba/__init__.py:142-151): 256 is the reference default
+  if (H == 256) MSOCR_LAUNCH(bilstm_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 128) MSOCR_LAUNCH(bilstm_kernel<128>, grid, dim3(128), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 512) MSOCR_LAUNCH(bilstm_kernel<512>, grid, dim3(512), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 64) MSOCR_LAUNCH(bilstm_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 192) MSOCR_LAUNCH(bilstm_kernel<192>, grid, dim3(192), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 320) MSOCR_LAUNCH(bilstm_kernel<320>, grid, dim3(320), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 384) MSOCR_LAUNCH(bilstm_kernel<384>, grid, dim3(384), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else if (H == 448) MSOCR_LAUNCH(bilstm_kernel<448>, grid, dim3(448), 0, (hipStream_t)stream, xproj, w_hh_t, B, T, hcat_out);
+  else return MSOCR_E_ARG;
   return LAUNCH_OK();
 }
 
@@ -664,8 +675,11 @@ __global__ void attn_beam_finalize_kernel(const float* __restrict__ ws_logits, c
       logits_out[((long)b * steps + t) * V + v] = ws_logits[(((long)b * steps + t) * K + path[t]) * V + v];
 }
 
+// shapes of the two fast kernels (one hidden unit per thread, logits of one row in 256 LDS floats)
+static bool attn_fast_shape(int T, int H, int V) { return H == ATT_H && V <= 256 && T <= 48; }
 static int check_attn(const float* bh, const float* ph, const msocr_attn_weights* w, int B, int T, int H, int V, int steps) {
-  if (!bh || !ph || !w || B <= 0 || T <= 0 || T > 48 || H != ATT_H || V <= 0 || V > 256 || steps <= 0 || steps > 64) return MSOCR_E_ARG;
+  if (!bh || !ph || !w || B <= 0 || T <= 0 || T > 64 || H < 64 || H > 512 || H % 64 || V <= 0 || V > 512 || steps <= 0 || steps > 64)
+    return MSOCR_E_ARG;
   if (!w->h2h_wt || !w->h2h_b || !w->score_w || !w->wih_ctx_t || !w->wih_tok || !w->whh_t || !w->b_gates || !w->gen_wt || !w->gen_b)
     return MSOCR_E_ARG;
   return MSOCR_OK;
@@ -680,6 +694,7 @@ extern "C" int msocr_attn_greedy(const float* batch_H, const float* proj_H, cons
   a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = 1;
   a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = 1.0f;
   a.logits_out = logits_out; a.ids_out = ids_out;
+  if (!attn_fast_shape(T, H, V)) return msocr_internal_attn_general(a, H, false, (hipStream_t)stream);
   const size_t lds = (size_t)2 * T * ATT_H * sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -725,7 +740,7 @@ static int attn_beam_impl(const float* batch_H, const float* proj_H, const float
                           int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
                           int32_t* chunk_state_dev, void* stream) {
   if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !fin_step_out || !workspace) return MSOCR_E_ARG;
-  if (beam < 1 || beam > ATT_KMAX || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
+  if (beam < 1 || beam > 16 || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
   AttnArgs a{};
   a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w; a.ctx_gates = ctx_gates;
   a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = beam;
@@ -737,6 +752,10 @@ static int attn_beam_impl(const float* batch_H, const float* proj_H, const float
   a.best_at = (int32_t*)p;
   a.fin_step = fin_step_out;
   if (chunk_id_dev && chunk_size_dev && chunk_state_dev) { a.chunk_id = chunk_id_dev; a.chunk_size = chunk_size_dev; a.chunk_state = chunk_state_dev; }
+  if (!attn_fast_shape(T, H, V) || beam > ATT_KMAX) {  // other hidden sizes, charsets above 256, beams above 8: the general kernel
+    if (ctx_gates) return MSOCR_E_ARG;
+    return msocr_internal_attn_general(a, H, true, (hipStream_t)stream);
+  }
   // NB = 2 batch rows per workgroup when their encoder rows fit in LDS beside the 68 KB of state (T <= 20), else 1
   // two batch rows per workgroup (two 256-thread halves sharing the weight stream through L1) when both rows' encoder
   // tiles fit in LDS beside 2 x 34 KB of state (T <= 20); MSOCR_BEAM_HB=1 forces one row per workgroup
@@ -774,7 +793,7 @@ static int attn_beam_impl(const float* batch_H, const float* proj_H, const float
 
 extern "C" int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                                         float* logits_out, int32_t* ids_out, void* stream) {
-  if (!workspace || !trun_dev || !logits_out || !ids_out || B <= 0 || V <= 0 || steps <= 0 || steps > 64 || beam < 1 || beam > ATT_KMAX)
+  if (!workspace || !trun_dev || !logits_out || !ids_out || B <= 0 || V <= 0 || steps <= 0 || steps > 64 || beam < 1 || beam > 16)
     return MSOCR_E_ARG;
   const char* p = (const char*)workspace;
   const float* wl = (const float*)p; p += beam_ws_logits(B, steps, beam, V);

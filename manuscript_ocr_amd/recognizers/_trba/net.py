@@ -48,10 +48,13 @@ LAYER_SPEC = (("layer1", 1, 2), ("layer2", 2, 1), ("layer3", 5, 2), ("layer4", 3
 
 class TrbaNet:
     def __init__(self, state_dict, num_classes, hidden=256, dtype=torch.float32, device="cuda", split=None):
-        if hidden != 256:
-            raise ValueError("the HIP recurrent/attention kernels are built for hidden_size=256 (the reference default)")
-        if num_classes > 256:
-            raise ValueError("charset larger than 256 tokens is not supported by the decoder kernel")
+        # hidden_size comes from the checkpoint's config.json (reference __init__.py:142-151, default 256).  256 / <= 256 tokens /
+        # beam <= 8 run on the fast decoder kernels; other multiples of 64 up to 512, charsets up to 512 tokens and beams up to 16
+        # (beam x hidden <= 4096) on the general one (csrc/attn_general.hip)
+        if hidden % 64 or not 64 <= hidden <= 512:
+            raise ValueError(f"hidden_size must be a multiple of 64 between 64 and 512 for the HIP recurrent / attention kernels, got {hidden}")
+        if num_classes > 512:
+            raise ValueError(f"charsets above 512 tokens are not supported by the decoder kernels, got {num_classes}")
         self.dtype, self.device = dtype, torch.device(device)
         self.V, self.Hd = num_classes, hidden
         dev, sd = self.device, state_dict
@@ -194,7 +197,10 @@ class TrbaNet:
                                                    dtype=torch.float32).to(self.device)
                 torch.cuda.synchronize()
             lp = self._lp_cache[key]
-        hoist = HOIST_CTX and os.environ.get("MSOCR_BEAM_MFMA", "1") != "0"
+        if not 1 <= beam_size <= 16 or (beam_size * H > 4096 and not (H == 256 and beam_size <= 8)):
+            raise ValueError(f"beam_size {beam_size} with hidden_size {H}: the decoder kernels take beam_size <= 16 and beam_size x hidden_size <= 4096")
+        fast = H == 256 and self.V <= 256 and T <= 48 and beam_size <= 8  # the matrix-core kernel's shapes
+        hoist = HOIST_CTX and fast and os.environ.get("MSOCR_BEAM_MFMA", "1") != "0"
         if hoist:  # W_ih[:, :H] batch_H_t for every frame, once per call instead of W_ih[:, :H] ctx in every step
             ctxg = self._gemm(batch_H.reshape(B * T, H), self.att["wih_ctx_rows"], None)
         e = ops._prof_begin()

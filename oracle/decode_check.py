@@ -12,7 +12,7 @@ Attention._beam_decode top-k (model.py:161-163) and final arg-max (model.py:218)
 TIE_TOL = 5e-3
 
 
-def oracle_decode_chunks(trba_net, x_all, mode, chunk=32, max_len=25, batch_H=None, keep_batch_H=None):
+def oracle_decode_chunks(trba_net, x_all, mode, chunk=32, max_len=25, batch_H=None, keep_batch_H=None, beam_size=8):
     """The reference's TRBA.predict loop (recognizers/_trba/__init__.py:374-412) on the CPU oracle: one model call per
     `chunk` rows.  Returns a list with one dict per row: ids [T_run], logits [T_run, V], and the margins of the decisions the
     oracle's own decode took for that row (oracle/trba_model.py `diag`).
@@ -32,7 +32,7 @@ def oracle_decode_chunks(trba_net, x_all, mode, chunk=32, max_len=25, batch_H=No
             if mode == "greedy":
                 lg, ids = trba_net.attn.greedy(enc, max_len, d)
             else:
-                lg, ids = trba_net.attn.beam(enc, max_len, 8, 0.9, 1.7, d)
+                lg, ids = trba_net.attn.beam(enc, max_len, beam_size, 0.9, 1.7, d)
         lg, ids = lg.numpy(), ids.numpy()
         for j in range(ids.shape[0]):
             r = {"ids": ids[j], "logits": lg[j], "chunk": c0 // chunk}
@@ -116,7 +116,7 @@ def row_logit_errors(rows_a, rows_b):
     return np.array(out)
 
 
-def calibrated_logit_bounds(trba_net, ref_batch_H, dev_batch_H, exp_rows, mode, chunk=32, max_len=25, draws=4, seed=0):
+def calibrated_logit_bounds(trba_net, ref_batch_H, dev_batch_H, exp_rows, mode, chunk=32, max_len=25, draws=4, seed=0, beam_size=8):
     """Where the device's decoder-logit error may lie, DERIVED instead of chosen: the device's encoder output differs from the
     oracle's by delta = dev_batch_H - ref_batch_H (measured, f32 rounding of a different summation order).  The oracle's own
     decoder is re-run on ref_batch_H + Gaussian noise whose per-row RMS equals that row's measured RMS of delta (`draws`
@@ -132,10 +132,10 @@ def calibrated_logit_bounds(trba_net, ref_batch_H, dev_batch_H, exp_rows, mode, 
     pooled = []
     for _ in range(draws):
         noise = rng.standard_normal(ref_batch_H.shape).astype(np.float32) * row_rms[:, None, None]
-        pert = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=ref_batch_H + noise)
+        pert = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=ref_batch_H + noise, beam_size=beam_size)
         pooled.append(row_logit_errors(pert, exp_rows))
     pooled = np.concatenate(pooled)
-    rows_on_dev = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=dev_batch_H)
+    rows_on_dev = oracle_decode_chunks(trba_net, None, mode, chunk, max_len, batch_H=dev_batch_H, beam_size=beam_size)
     on_dev = row_logit_errors(rows_on_dev, exp_rows)
     factor = 2.0
     return {"oracle_noise": pooled, "oracle_on_dev_H": on_dev, "factor": factor,
