@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   // One LDS stage, two barriers per K-tile, 3 workgroups per CU.  Measured alternatives (round 3, gpurun_out/r3_split_variants.txt,
   // f32-equivalent TFLOP/s at K = 512 / 4096 on M = 161280, N = 512): this loop 156 / 182; two LDS stages with K-tiles of 16 (one
   // barrier per tile, 3 per CU) 145 / 148; two stages with K-tiles of 32 (1 per CU) 120 / 148; K-tiles of 16 at 4 per CU 126 / 94;
-  // 2 per CU 154 / 176.  Timing ablations of this loop: MFMAs + fragment reads alone 266, + restaging 228, + loads that always hit
-  // the cache 190.
+  // 2 per CU 154 / 176; the weight planes straight into LDS (global_load_lds_dwordx4, double-buffered, 2 per CU) 158 / 189 against
+  // 166 / 191 for this loop on the same box.  Timing ablations of this loop: MFMAs + fragment reads alone 266, + restaging 228,
+  // + loads that always hit the cache 190.
   for (int kt = 0; kt < p.ktiles; ++kt) {
     if (kt + 1 < p.ktiles) load_tile(kt + 1);  // global loads in flight under the MFMAs
     compute(0);
