@@ -125,6 +125,12 @@ int msocr_conv3x3_winograd42_fused(const msocr_conv_desc* d, const void* in, con
                                    const void* residual, void* out, void* workspace, void* stream);
 int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, const float* u_weight, const void* workspace, const float* bias,
                                        const void* residual, void* out, void* stream);
+/* The same two entry points with the 24 K = 64 GEMMs on the bf16 matrix pipes (split-operand arithmetic, see msocr_conv1x1_split):
+ * u_planes = [3][24][Cout][64] bf16 = msocr_split_bf16x3_host of msocr_winograd42_weights_host's output. */
+int msocr_conv3x3_winograd42_fused_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                         const void* residual, void* out, void* workspace, void* stream);
+int msocr_winograd42_fused_gemm_output_split(const msocr_conv_desc* d, const void* u_planes, const void* workspace, const float* bias,
+                                             const void* residual, void* out, void* stream);
 
 /* u8 RGB images (N x H x W x 3) -> normalised NHWC with C padded 3->cpad (4 or 8) inside a zero canvas
  * out[N][Hp][Wp][cpad], image origin at (pad_t, pad_l); the zero border is the stem convolution's padding.

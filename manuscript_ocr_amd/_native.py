@@ -62,6 +62,8 @@ _SIGS = {
     "msocr_conv3x3_winograd42_fused_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd42_fused": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_fused_gemm_output": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd42_fused_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_winograd42_fused_gemm_output_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_normalize_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_resize_linear_u8": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "msocr_maxpool2d": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_vp]),

@@ -88,8 +88,7 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   // load), so the loop holds 4 + B_IT address registers instead of ten 64-bit pointers — the 168-register budget of 3 workgroups per
   // CU then leaves no spill in the loop (a spilled, freshly loaded register made every K-tile wait for a memory round trip).
   const int a_chunk = tid % ACH, a_row0 = tid / ACH;
-  const char* a_ptr[GEN ? A_IT : 1];
-  uint32_t a_off[GEN ? 1 : A_IT];
+  uint32_t a_off[A_IT];  // GEN: signed byte offset of the row's (ho*SH - PH, wo*SW - PW) pixel, < 2 GB in magnitude (host check)
   int a_hi0[GEN ? A_IT : 1], a_wi0[GEN ? A_IT : 1];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       a_hi0[i] = ho * p.SH - p.PH;
       a_wi0[i] = wo * p.SW - p.PW;
-      a_ptr[i] = g_in + ((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_chunk * 4) * 4;
+      a_off[i] = (uint32_t)(int32_t)(((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_chunk * 4) * 4);
     } else {
       // 1x1 / stride 1 / no padding: row m of the GEMM is pixel m of the NHWC input (row stride sW elements); < 4 GB (host check)
       a_off[i] = (uint32_t)((m * p.sW + a_chunk * 4) * 4);
@@ -122,12 +121,15 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   u32x4 ra[A_IT], rb[3][B_IT];
   auto load_tile = [&](int kt) {
     if constexpr (GEN) {
-      const long koff = ((long)t_kh * p.sH + (long)t_kw * p.sW + t_c0) * 4;
+      const int32_t koff = (int32_t)(((long)t_kh * p.sH + (long)t_kw * p.sW + t_c0) * 4);  // uniform
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int hi = a_hi0[i] + t_kh, wi = a_wi0[i] + t_kw;
         const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[i] = *reinterpret_cast<const u32x4*>(ok ? a_ptr[i] + koff : reinterpret_cast<const char*>(msocr_split_zero16));
+        // 32-bit offsets kept in registers, the 64-bit address formed per load: four address registers less than four pointers, which
+        // is what keeps this loop free of spill reloads at 168 registers
+        const char* src = g_in + (long)(int32_t)(a_off[i] + (uint32_t)koff);
+        ra[i] = *reinterpret_cast<const u32x4*>(ok ? src : reinterpret_cast<const char*>(msocr_split_zero16));
       }
       t_c0 += BK;
       if (t_c0 == p.Cin) {
@@ -383,7 +385,24 @@ extern "C" int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, cons
   p.has_res = has_res ? 1 : 0;
   p.nbatch = 1; p.bsA = p.bsW = p.bsO = 0;
   p.wplane = (long)d->Cout * p.Ktot;
-  return launch_split_any(p, (hipStream_t)stream, true);
+  // the general loader keeps signed 32-bit byte offsets from the input pointer: a batch whose input extent reaches 2 GB is launched
+  // image range by image range (outputs of different images are independent)
+  const long img_bytes = (long)d->in_sN * 4;
+  if (img_bytes >= (1L << 31)) return MSOCR_E_ARG;
+  const int per = (int)(((1L << 31) - 1) / (img_bytes > 0 ? img_bytes : 1));
+  if (d->N <= per) return launch_split_any(p, (hipStream_t)stream, true);
+  const long out_img = (long)d->Ho * d->Wo * d->out_ld * 4, res_img = (long)d->Ho * d->Wo * d->res_ld * 4;
+  for (int n0 = 0; n0 < d->N; n0 += per) {
+    ConvParams q = p;
+    q.N = d->N - n0 < per ? d->N - n0 : per;
+    q.M = (long)q.N * d->Ho * d->Wo;
+    q.in = p.in + (long)n0 * img_bytes;
+    q.out = p.out + (long)n0 * out_img;
+    if (has_res) q.res = p.res + (long)n0 * res_img;
+    const int rc = launch_split_any(q, (hipStream_t)stream, true);
+    if (rc != MSOCR_OK) return rc;
+  }
+  return MSOCR_OK;
 }
 
 // nbatch independent GEMMs of one shape in ONE launch, C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]: A f32 [nbatch][M][K],

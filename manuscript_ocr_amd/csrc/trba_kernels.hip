@@ -72,6 +72,8 @@ __device__ __forceinline__ void st4<uint16_t>(uint16_t* p, f32x4 v) {
   *reinterpret_cast<uint2*>(p) = o;
 }
 
+// Measured and dropped (round 3): keeping the summed x values of a 4 x 13 map in registers (26 x 16 B per thread) so that the scale
+// pass does not read x again — 0.118 against 0.091 ms per 960 crops: the second read hits L2, and 163 registers cost occupancy.
 template <typename T>
 __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ x, const T* __restrict__ idt, int HW, int C,
                                                            const float* __restrict__ w1, const float* __restrict__ w2,

@@ -404,13 +404,32 @@ typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 #define WINO_FUSED_PFD 3
 #endif
 
-template <bool POOL>
-__global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __restrict__ V, const float* __restrict__ U, int Cout,
+// SPLIT = true (round 3): the 24 K = 64 GEMMs on the bf16 matrix pipes with exactly split operands (conv_split.hip has the
+// arithmetic): V is split in registers on the way into LDS, U arrives as three bf16 planes [3][24][Cout][64]; per point and wave
+// 12 x v_mfma_f32_16x16x32_bf16 (192 cycles) replace 16 x v_mfma_f32_16x16x4_f32 (512 cycles).  Same accumulator layout, so the
+// output transform below is shared.
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int wino_split_step(float& x, float& y) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x, y};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const unsigned int pk = __builtin_bit_cast(unsigned int, h);
+  x -= __uint_as_float(pk << 16);
+  y -= __uint_as_float(pk & 0xffff0000u);
+  return pk;
+}
+
+template <bool POOL, bool SPLIT = false>
+__global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __restrict__ V, const void* __restrict__ Uv, int Cout,
                                                                  WinoGeom g, const float* __restrict__ bias,
                                                                  const float* __restrict__ res, long res_ld, int relu,
                                                                  float* __restrict__ out, long out_ld) {
-  constexpr int K = 64, BM = 32, BN = 32, ROWB = K * 4;  // 256-byte tile rows, 16 chunks of 16 B
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * ROWB];
+  constexpr int K = 64, BM = 32, BN = 32, ROWB = K * 4;  // exact form: 256-byte tile rows, 16 chunks of 16 B
+  constexpr int ROWS = 128, PLANE = BM * ROWS;           // split form: six [32 rows][64 bf16 = 128 B] planes per stage
+  constexpr int STAGE_BYTES = SPLIT ? 6 * PLANE : (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave >> 1, nj = wave & 1;
   const int r16 = lane & 15, kg = lane >> 4;
@@ -426,7 +445,83 @@ __global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __r
   const int nb = (int)(bid % nbn);
   const long m0 = (bid / nbn) * BM;
   const int n0 = nb * BN;
+  f32x4 acc[24];
 
+  if constexpr (SPLIT) {
+    const unsigned short* U = reinterpret_cast<const unsigned short*>(Uv);
+    // staging: V as the exact form (row = tid / 16 (+16), 16-B chunk of 4 f32 = tid % 16); U planes: row = tid / 8, 16-B chunk of 8 bf16 = tid % 8
+    const int chunk = tid & 15, row0 = tid >> 4;
+    const int bchunk = tid & 7, brow = tid >> 3;
+    const long planeV = g.Mt * (long)K, planeU = (long)Cout * K, uplane = 24 * planeU;
+    const float* pa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long m = m0 + row0 + 16 * i;
+      if (m >= g.Mt) m = g.Mt - 1;  // valid memory; the rows are never stored
+      pa[i] = V + m * K + chunk * 4;
+    }
+    const unsigned short* pb = U + (long)(n0 + brow) * K + bchunk * 8;
+    constexpr int PFD = 2;
+    u32x4w ra[PFD][2], rb[PFD][3];
+    auto gload = [&](int p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[p % PFD][i] = *reinterpret_cast<const u32x4w*>(pa[i] + p * planeV);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rb[p % PFD][pl] = *reinterpret_cast<const u32x4w*>(pb + pl * uplane + p * planeU);
+    };
+    auto sstore = [&](int p) {
+      unsigned char* st = &smem[p & 1][0];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 16 * i;
+        float x0 = __uint_as_float(ra[p % PFD][i][0]), x1 = __uint_as_float(ra[p % PFD][i][1]);
+        float x2 = __uint_as_float(ra[p % PFD][i][2]), x3 = __uint_as_float(ra[p % PFD][i][3]);
+        unsigned char* dst = st + row * ROWS + (((chunk >> 1) ^ (row & 7)) << 4) + ((chunk & 1) << 3);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          u32x2w v;
+          v[0] = wino_split_step(x0, x1);
+          v[1] = wino_split_step(x2, x3);
+          *reinterpret_cast<u32x2w*>(dst + pl * PLANE) = v;
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4w*>(st + (3 + pl) * PLANE + brow * ROWS + ((bchunk ^ (brow & 7)) << 4)) = rb[p % PFD][pl];
+    };
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) gload(q);
+    sstore(0);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 24; ++p) {
+      if (p + PFD < 24) gload(p + PFD);
+      const unsigned char* st = &smem[p & 1][0];
+      const int rowa = mi * 16 + r16, rowb = nj * 16 + r16;
+      f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two k32 steps; lane (r16, kg) takes k = 32 ks + 8 kg + 0..7 of its row for both operands
+        const int c = 4 * ks + kg;
+        bf16x8w fa[3], fb[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[pl] = *reinterpret_cast<const bf16x8w*>(st + pl * PLANE + rowa * ROWS + ((c ^ (rowa & 7)) << 4));
+          fb[pl] = *reinterpret_cast<const bf16x8w*>(st + (3 + pl) * PLANE + rowb * ROWS + ((c ^ (rowb & 7)) << 4));
+        }
+        // smallest terms first
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], c4, 0, 0, 0);
+      }
+      acc[p] = c4;
+      if (p + 1 < 24) sstore(p + 1);
+      __syncthreads();
+    }
+  } else {
+  const float* U = reinterpret_cast<const float*>(Uv);
   // staging coordinates: thread -> (row = tid / 16 (+16 on the second pass), 16-B chunk = tid % 16)
   const int chunk = tid & 15, row0 = tid >> 4;
   const long planeV = g.Mt * (long)K, planeU = (long)Cout * K;
@@ -457,7 +552,6 @@ __global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __r
       *reinterpret_cast<u32x4w*>(&smem[p & 1][(BM + row) * ROWB + ((chunk ^ (row & 15)) << 4)]) = rb[p % PFD][i];
     }
   };
-  f32x4 acc[24];
 #pragma unroll
   for (int q = 0; q < PFD; ++q) gload(q);
   sstore(0);
@@ -487,6 +581,8 @@ __global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __r
     acc[p] = c4;
     if (p + 1 < 24) sstore(p + 1);
     __syncthreads();
+  }
+
   }
 
   // ---- output transform in registers: lane holds rows (tiles) 4 * kg + e, column (cout) r16 of its wave's 16x16 block ----
@@ -564,8 +660,23 @@ extern "C" int64_t msocr_conv3x3_winograd42_fused_workspace_bytes(const msocr_co
 }
 
 // stage 2 of msocr_conv3x3_winograd42_fused (stage 1 is msocr_winograd42_input_transform): V in the workspace -> out
+static int wino42_fused_launch(const msocr_conv_desc* d, const void* u_weight, bool split, const void* workspace, const float* bias,
+                               const void* residual, void* out, void* stream);
+
 extern "C" int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, const float* u_weight, const void* workspace,
                                                   const float* bias, const void* residual, void* out, void* stream) {
+  return wino42_fused_launch(d, u_weight, false, workspace, bias, residual, out, stream);
+}
+
+// the same with U as three bf16 planes [3][24][Cout][64] (msocr_split_bf16x3_host of msocr_winograd42_weights_host's output): the
+// GEMMs run on the bf16 matrix pipes with exactly split operands
+extern "C" int msocr_winograd42_fused_gemm_output_split(const msocr_conv_desc* d, const void* u_planes, const void* workspace,
+                                                        const float* bias, const void* residual, void* out, void* stream) {
+  return wino42_fused_launch(d, u_planes, true, workspace, bias, residual, out, stream);
+}
+
+static int wino42_fused_launch(const msocr_conv_desc* d, const void* u_weight, bool split, const void* workspace, const float* bias,
+                               const void* residual, void* out, void* stream) {
   WinoGeom g;
   if (wino42_fused_check(d, &g) != MSOCR_OK || !u_weight || !workspace || !out) return MSOCR_E_ARG;
   if (((uintptr_t)workspace | (uintptr_t)u_weight) & 15) return MSOCR_E_ARG;
@@ -574,12 +685,17 @@ extern "C" int msocr_winograd42_fused_gemm_output(const msocr_conv_desc* d, cons
   const long nblk = ((g.Mt + 31) / 32) * (long)(d->Cout / 32);
   if (nblk <= 0 || nblk > 0x7fffffffL) return MSOCR_E_ARG;
   const int relu = (d->flags & MSOCR_CONV_RELU) ? 1 : 0;
-  if (d->flags & MSOCR_CONV_POOL2)
-    MSOCR_LAUNCH(wino42_fused64_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, u_weight,
-                 d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
-  else
-    MSOCR_LAUNCH(wino42_fused64_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, u_weight,
-                 d->Cout, g, bias, has_res ? (const float*)residual : nullptr, (long)d->res_ld, relu, (float*)out, (long)d->out_ld);
+  const float* rp = has_res ? (const float*)residual : nullptr;
+  const dim3 grid((unsigned)nblk), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float* ws = (const float*)workspace;
+  if (d->flags & MSOCR_CONV_POOL2) {
+    if (split) MSOCR_LAUNCH((wino42_fused64_kernel<true, true>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
+    else MSOCR_LAUNCH((wino42_fused64_kernel<true, false>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
+  } else {
+    if (split) MSOCR_LAUNCH((wino42_fused64_kernel<false, true>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, rp, (long)d->res_ld, relu, (float*)out, (long)d->out_ld);
+    else MSOCR_LAUNCH((wino42_fused64_kernel<false, false>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, rp, (long)d->res_ld, relu, (float*)out, (long)d->out_ld);
+  }
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 
@@ -594,6 +710,19 @@ extern "C" int msocr_conv3x3_winograd42_fused(const msocr_conv_desc* d, const vo
                (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
   if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
   return msocr_winograd42_fused_gemm_output(d, u_weight, workspace, bias, residual, out, stream);
+}
+
+extern "C" int msocr_conv3x3_winograd42_fused_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                                    const void* residual, void* out, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino42_fused_check(d, &g) != MSOCR_OK || !in || !workspace || !u_planes) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const long nb_in = (g.Mt * (d->Cin / 4) + 255) / 256;
+  if (nb_in > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino42_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, (hipStream_t)stream, (const float*)in, (long)d->in_sN,
+               (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
+  if (hipGetLastError() != hipSuccess) return MSOCR_E_LAUNCH;
+  return msocr_winograd42_fused_gemm_output_split(d, u_planes, workspace, bias, residual, out, stream);
 }
 
 // U[xi*4+nu][co][c] = sum_{kh,kw} G6[xi][kh] G4[nu][kw] w[co][kh][kw][c] (xi = 0..5 on the kernel's H axis), f64, rounded once.

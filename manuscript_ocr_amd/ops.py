@@ -157,6 +157,10 @@ def attach_winograd(w, split=None):
         u42 = torch.empty((24, Cout, Cin), dtype=torch.float32)
         nat.check(nat.lib().msocr_winograd42_weights_host(wh.data_ptr(), Cout, Cin, u42.data_ptr()), "winograd42_weights_host")
         w._msocr_wino42_fused = u42.to(w.device)
+        # the K = 64 GEMMs on the bf16 pipes pay only for the wide layer (TRBA conv0b, 64 -> 128 + pool: 2.43 -> 2.21 ms per 960 crops);
+        # with 64 output channels the kernel is bound by staging and barriers either way (0.84 -> 0.86 ms) and stays exact
+        if (SPLIT_BF16X3 if split is None else split) and Cout >= 128:
+            w._msocr_wino42_fused_split = split_planes(u42).to(w.device)  # [3][24][Cout][64] bf16
         return w
     if not (WINOGRAD_MIN_CIN and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin >= WINOGRAD_MIN_CIN and Cin % 16 == 0
             and Cout % 32 == 0):
@@ -202,7 +206,11 @@ def _conv3x3_fused64(x, w, u42, bias, relu, residual, pool2, out):
     per = -(-N // parts)
     ws = _wino_workspace(nbytes if parts == 1 else (nbytes // N) * per, x.device)
     bp = bias.data_ptr() if bias is not None else None
-    what = f"msocr_conv3x3_winograd42_fused {tuple(x.shape)} * {tuple(w.shape)}"
+    up = getattr(w, "_msocr_wino42_fused_split", None) if SPLIT_BF16X3 else None
+    f_whole, f_gemm, name = L.msocr_conv3x3_winograd42_fused, L.msocr_winograd42_fused_gemm_output, "winograd42_fused"
+    if up is not None:  # the 24 K = 64 GEMMs on the bf16 pipes with exactly split operands
+        u42, f_whole, f_gemm, name = up, L.msocr_conv3x3_winograd42_fused_split, L.msocr_winograd42_fused_gemm_output_split, "winograd42_fused_split"
+    what = f"msocr_conv3x3_{name} {tuple(x.shape)} * {tuple(w.shape)}"
     TH, TW = (H + 3) // 4, (W + 1) // 2
     alg = 2.0 * N * H * W * Cout * 9 * Cin
     for n0 in range(0, N, per):
@@ -210,15 +218,15 @@ def _conv3x3_fused64(x, w, u42, bias, relu, residual, pool2, out):
         d.N = n1 - n0
         xp, rp_, op = x[n0:n1].data_ptr(), (residual[n0:n1].data_ptr() if residual is not None else None), out[n0:n1].data_ptr()
         if PROFILE is None:
-            nat.check(L.msocr_conv3x3_winograd42_fused(ctypes.byref(d), xp, u42.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
+            nat.check(f_whole(ctypes.byref(d), xp, u42.data_ptr(), bp, rp_, op, ws.data_ptr(), _stream()), what)
         else:
             nn, mt = n1 - n0, (n1 - n0) * TH * TW
             e = _prof_begin()
             nat.check(L.msocr_winograd42_input_transform(ctypes.byref(d), xp, ws.data_ptr(), _stream()), what)
             _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + 24 * mt * Cin), (mt, Cin))
             e = _prof_begin()
-            nat.check(L.msocr_winograd42_fused_gemm_output(ctypes.byref(d), u42.data_ptr(), ws.data_ptr(), bp, rp_, op, _stream()), what)
-            _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 24 * mt * Cin * Cout), (nn * H * W, Cout, 9 * Cin, "winograd42_fused"))
+            nat.check(f_gemm(ctypes.byref(d), u42.data_ptr(), ws.data_ptr(), bp, rp_, op, _stream()), what)
+            _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 24 * mt * Cin * Cout), (nn * H * W, Cout, 9 * Cin, name))
     return out
 
 

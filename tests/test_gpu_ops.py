@@ -227,11 +227,13 @@ FUSED64_CASES = [
 ]
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("case", FUSED64_CASES)
-def test_conv3x3_fused64_winograd_vs_direct_and_f64(ops, case):
+def test_conv3x3_fused64_winograd_vs_direct_and_f64(ops, case, split, monkeypatch):
     """Cin = 64 layers: tall Winograd with GEMMs + output transform (+ 2x2 max-pool) fused in one kernel (wino42_fused64_kernel)
     against an f64 convolution (+ residual, ReLU, max_pool2d): 2e-5 bound, within 8x of the direct kernel's own error; the
     pooled result also equals max-pooling the kernel's own unpooled result exactly."""
+    monkeypatch.setattr(ops, "SPLIT_BF16X3", split)  # 1: the K = 64 GEMMs on the bf16 pipes (wino42_fused64_kernel<POOL, true>)
     N, H, W, Cout, relu, use_res, pool = case
     Cin = 64
     g = torch.Generator().manual_seed(sum(case[:4]) + 7)
@@ -251,6 +253,8 @@ def test_conv3x3_fused64_winograd_vs_direct_and_f64(ops, case):
     w_direct = ops.attach_split(_w_khwc(w, torch.float32), False)  # the exact-f32 direct kernel
     w_f = ops.attach_winograd(_w_khwc(w, torch.float32))
     assert getattr(w_f, "_msocr_wino42_fused", None) is not None and getattr(w_f, "_msocr_wino", None) is None
+    if split and not hasattr(w_f, "_msocr_wino42_fused_split"):  # narrow layers keep the exact GEMMs by default: force the planes here
+        w_f._msocr_wino42_fused_split = ops.split_planes(w_f._msocr_wino42_fused)
     out_d = ops.conv2d(xd, w_direct, b.cuda(), (1, 1), (1, 1), relu, rd)
     oh, ow = (H // 2, W // 2) if pool else (H, W)
     big = torch.full((N, oh, ow, Cout + 32), 7.0, device="cuda")  # written into a channel slice
