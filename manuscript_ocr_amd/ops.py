@@ -122,10 +122,11 @@ def split_planes(t):
     return planes.view(torch.bfloat16).to(t.device)
 
 
-# Below this reduction length (KH * KW * Cin) a convolution stays on the exact-f32 kernel: measured on the MI355X (round 3,
-# profiles/r03_conv_layers_split_all.txt) the split kernel's K-tiles of 32 with two barriers each lose to the exact lean kernel's
-# K-tiles of 16 at K = 64 (55 against 64 TFLOP/s) and K = 128 (83 against 91), and win from K = 256 up.
-SPLIT_MIN_K = int(os.environ.get("MSOCR_SPLIT_MIN_K", "256"))
+# Below this reduction length (KH * KW * Cin) a convolution stays on the exact-f32 kernel: the split kernel's K-tiles of 32 with two
+# barriers each lose to the exact lean kernel's K-tiles of 16 at K = 64 (55 against 64 TFLOP/s, profiles/r03_conv_layers_split_all.txt;
+# these layers sit at 0.78 of their HBM roofline anyway).  Whole pipeline, same box, after the split kernel lost its spill:
+# 70.4 / 70.9 / 71.2 pages/s with the threshold at 256 / 192 / 128.
+SPLIT_MIN_K = int(os.environ.get("MSOCR_SPLIT_MIN_K", "128"))
 
 
 def _split_eligible(w):
