@@ -245,14 +245,29 @@ int msocr_attn_beam(const float* batch_H, const float* proj_H, const msocr_attn_
                     int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
                     int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
                     const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
+/* Optional split form of the three per-step weight matrices (device pointers, each packed by msocr_attn_pack_split_host and
+ * copied to the device by the caller): with it the matrix-core kernel forms every f32 product from three bf16 terms per
+ * operand on the bf16 matrix pipe (six partial products, f32 accumulation: f32 result up to 2^-25 relative per product and the
+ * order of summation) instead of the 1/16-rate exact-f32 MFMA.  NULL = exact-f32 products. */
+typedef struct msocr_attn_split_weights {
+  const uint16_t* h2h_p;  /* from h2h_wt, N = H */
+  const uint16_t* whh_p;  /* from whh_t,  N = 4 H, gate_interleaved */
+  const uint16_t* gen_p;  /* from gen_wt, N = V */
+} msocr_attn_split_weights;
+
 /* msocr_attn_beam with the context half of the LSTMCell input product hoisted out of the step loop (matrix-core kernel only):
  * ctx_gates [B][T][H][4] f32 = batch_H x rnn.weight_ih[:, :H]^T with the four gates of a unit adjacent (row j*4+g of the
  * product), computed once per call by a GEMM (msocr_conv1x1_split).  W_ih[:, :H] (sum_t alpha_t batch_H_t) == sum_t alpha_t
  * (W_ih[:, :H] batch_H_t): same result up to f32 summation order, half the matrix work per step. */
-int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B,
-                            int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id,
-                            int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
-                            const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
+int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                            const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int beam, const float* lp_dev,
+                            float temperature, int sos_id, int eos_id, int blank_id, int32_t* fin_step_out, void* workspace,
+                            const int32_t* chunk_id_dev, const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
+/* Packing of a decoder weight for the fields of msocr_attn_split_weights; HOST memory in and out.  wt: [256][N] f32 row-major (h2h_wt,
+ * gen_wt) or, with gate_interleaved != 0, [256][N/4][4] (whh_t).  out: msocr_attn_pack_split_elems(N) = 3 * 256 * ceil32(N)
+ * uint16 (bf16 bit patterns), laid out [plane][k / 16][column][k % 16] with wt == plane0 + plane1 + plane2 exactly. */
+int64_t msocr_attn_pack_split_elems(int N);
+int msocr_attn_pack_split_host(const float* wt_host, int N, int gate_interleaved, uint16_t* out_host);
 int msocr_attn_beam_finalize(const void* workspace, int B, int V, int steps, int beam, const int32_t* trun_dev,
                              float* logits_out, int32_t* ids_out, void* stream);
 

@@ -40,6 +40,10 @@ class AttnWeights(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("h2h_wt", "h2h_b", "score_w", "wih_ctx_t", "wih_tok", "whh_t", "b_gates", "gen_wt", "gen_b")]
 
 
+class AttnSplitWeights(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("h2h_p", "whh_p", "gen_p")]
+
+
 _SIGS = {
     "msocr_conv2d": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
@@ -79,7 +83,9 @@ _SIGS = {
                                   c_vp, c_vp, c_vp]),
     "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,
                                 c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "msocr_attn_beam_hoisted": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,
+    "msocr_attn_pack_split_elems": (c_i64, [c_i32]),
+    "msocr_attn_pack_split_host": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "msocr_attn_beam_hoisted": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(AttnWeights), ctypes.POINTER(AttnSplitWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,
                                         c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_attn_beam_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "msocr_attn_beam_finalize": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),

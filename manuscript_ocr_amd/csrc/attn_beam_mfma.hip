@@ -1,5 +1,7 @@
 // attn_beam_mfma.hip — beam-search attention decode of the TRBA recogniser with the step's three matrix products on
-// the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 products and sums).
+// the matrix cores: in the split-operand form (default, precision "fp32": every f32 operand as three bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 partial products per 16 k, f32 accumulation) or on the exact-f32 pipe (v_mfma_f32_32x32x2_f32,
+// precision "fp32-exact" or no msocr_attn_split_weights).
 //
 // One 512-thread workgroup owns NB = 4 crops x 8 beam slots = 32 state rows for the whole step loop (rows of different
 // crops are independent: no inter-workgroup hand-off).  32 rows are exactly one MFMA row block, so every weight element a
@@ -40,6 +42,7 @@ extern "C" int msocr_attn_timing_read(unsigned long long* out_host) {
 #else
 #define TSTAMP(ph) do { } while (0)
 #endif
+
 
 namespace {
 
@@ -108,6 +111,24 @@ __device__ __forceinline__ void wave_argmax63(float& v, int& i) {
   argmax_step<DPP_MIRROR>(v, i);
   argmax_step<DPP_BCAST15, 0xA>(v, i);
   argmax_step<DPP_BCAST31, 0xC>(v, i);
+}
+
+// One-register f32 add / fused multiply-add that the compiler cannot pair into v_pk_add_f32 / v_pk_fma_f32.  The VALU work between
+// the softmax barrier and the gate MFMAs (token-row initialisation, the hoisted context sum) runs while faster waves of the same SIMD
+// are already inside their v_mfma_f32_32x32x16_bf16 loop.  Measured on MI355X (tools/attn_var.sh, 4 x 15360 state rows per form):
+// with the packed form of that sum — v_pk_fma_f32 ... op_sel:[0,1,0], the low result taking the high dword of a source pair — about
+// 0.5 % of the rows of the LAST crop processed came out with the low result of lanes 48..63 wrong (gate pre-activation off by 0.1 .. 1),
+// always there and only there, moving with the processing order of the crops; with one-register FMAs: 0 of 61440.  The same source
+// compiled for the exact-f32 kernel (16-pass f32 MFMAs beside it) never showed it.  tests/test_gpu_trba.py keeps a split-against-
+// exact comparison of every beam's logits as the guard.
+__device__ __forceinline__ float add_np(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fmac_np(float a, float b, float c) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
+  return c;
 }
 
 // row of accumulator register e in the 32x32 MFMA output layout (lane half = lane >> 5)
@@ -190,17 +211,110 @@ __device__ __forceinline__ void mfma_gates(const float* __restrict__ sX, int k0,
   }
 }
 
+// ---- split-operand form of the three matrix products (SPLITW): h is kept in LDS as three bf16 planes with h == p0 + p1 + p2
+// exactly (the residual chain of conv_split.hip), the weights come pre-split and packed [plane][k / 16][column][16] bf16
+// (msocr_attn_pack_split_host), and every f32 product a * b is the six bf16 products a2b0 + a0b2 + a1b1 + a1b0 + a0b1 + a0b0 on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation (dropped terms <= 2^-25 |a b|): 6 MFMAs of 8 passes per 16 k instead of 8 MFMAs of
+// 16 passes on the exact-f32 pipe, i.e. 2.7x less matrix-pipe time for the same f32 result up to summation order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PSB = H * 2 + 16;       // bytes per plane row: 528 = 132 dwords, rows shift 4 banks -> ds_read_b128 of 32 rows is conflict-free
+constexpr int PPL = R * PSB;          // bytes per plane
+
+__device__ __forceinline__ uint32_t split_pair(float& x, float& y) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x, y};
+  const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, RNE
+  x -= __uint_as_float(pk << 16);
+  y -= __uint_as_float(pk & 0xffff0000u);
+  return pk;
+}
+__device__ __forceinline__ void mma6(const bf16x8 (&fa)[3], const u32x4 (&wb)[3], f32x16& acc) {
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, wb[0]), b1 = __builtin_bit_cast(bf16x8, wb[1]), b2 = __builtin_bit_cast(bf16x8, wb[2]);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], b0, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void read_a3(const unsigned char* sP, int kb, int r32, int half, bf16x8 (&fa)[3]) {
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(sP + pl * PPL + r32 * PSB + kb * 32 + half * 16);
+}
+
+// D[32 rows][32 columns of this wave] += h * W, W packed [3][16][ncols][16] bf16
+__device__ __forceinline__ void mfma_cols32_split(const unsigned char* __restrict__ sP, const uint16_t* __restrict__ Wp, int ncols, int col,
+                                                  bool col_ok, int r32, int half, f32x16& acc) {
+  constexpr int PF = 4;  // k-blocks (of 16) of weight loads kept in flight
+  const int kbstep = ncols * 32, plstep = 16 * kbstep;  // bytes
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 3 * plstep, 0x00020000);
+  const int voff = col_ok ? col * 32 + half * 16 : 0x7ffffff0;
+  u32x4 wb[PF][3];
+#pragma unroll
+  for (int pq = 0; pq < PF; ++pq)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wb[pq][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, pl * plstep + pq * kbstep, 0);
+#pragma unroll 1
+  for (int kb0 = 0; kb0 < H / 16; kb0 += PF) {
+#pragma unroll
+    for (int pq = 0; pq < PF; ++pq) {
+      const int kb = kb0 + pq;
+      bf16x8 fa[3];
+      read_a3(sP, kb, r32, half, fa);
+      u32x4 cur[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) cur[pl] = wb[pq][pl];
+      if (kb + PF < H / 16) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wb[pq][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, pl * plstep + (kb + PF) * kbstep, 0);
+      }
+      mma6(fa, cur, acc);
+    }
+  }
+}
+
+// gates of hidden units 32w..32w+31: acc[g] += h * W_hh, packed [3][16][4 H (column g * H + j)][16] bf16
+__device__ __forceinline__ void mfma_gates_split(const unsigned char* __restrict__ sP, const uint16_t* __restrict__ Wp, int j, int r32, int half,
+                                                 f32x16 (&acc)[4]) {
+  constexpr int kbstep = 4 * H * 32, plstep = 16 * kbstep, gstep = H * 32;  // bytes
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 3 * plstep, 0x00020000);
+  const int voff = j * 32 + half * 16;
+  u32x4 wb[4][3];  // one k-block of the four gates; a gate's next block is requested as soon as its six MFMAs are issued
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wb[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, pl * plstep + g * gstep, 0);
+#pragma unroll 2
+  for (int kb = 0; kb < H / 16; ++kb) {
+    bf16x8 fa[3];
+    read_a3(sP, kb, r32, half, fa);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      mma6(fa, wb[g], acc[g]);
+      if (kb + 1 < H / 16) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          wb[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, pl * plstep + (kb + 1) * kbstep + g * gstep, 0);
+      }
+    }
+  }
+}
+
 // HOIST: the context half of the LSTMCell input product is hoisted out of the step loop.  The reference computes
 // gates = W_ih [ctx ; onehot] + W_hh h with ctx = sum_t alpha_t batch_H_t (model.py:40-45); since W_ih[:, :H] ctx =
 // sum_t alpha_t (W_ih[:, :H] batch_H_t), the products P_t = W_ih[:, :H] batch_H_t are computed ONCE per crop by a GEMM before the
 // kernel (a.ctx_gates, [B][T][H][4]) and a step only forms sum_t alpha_t P_t on the VALU (13 x 1024 FMAs per row instead of
 // 256 x 1024 MACs): half of the step's matrix work, 1 of its 2.5 MB of weights and the ctx phase (d) disappear.  Same arithmetic
 // up to the order of the f32 summation.
-template <bool HOIST>
+// SPLITW (with HOIST): the three matrix products in the split-operand form above; h lives only as its three bf16 planes.
+template <bool HOIST, bool SPLITW>
 __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
+  static_assert(HOIST || !SPLITW, "the split form is built for the hoisted kernel");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sX = lds;                 // [R][XS]   ctx (0..255) | h (256..511)
-  float* sbuf = sX + R * XS;       // [R][H]    ph, then logits, then scratch of the state permutation
+  float* sX = lds;                 // [R][XS]   ctx (0..255) | h (256..511)        (exact form)
+  unsigned char* sP = reinterpret_cast<unsigned char*>(lds);  // [3][R][PSB] bf16 planes of h  (split form)
+  float* sbuf = SPLITW ? lds + 3 * PPL / 4 : sX + R * XS;     // [R][H]    ph, then logits, then scratch of the state permutation
   float* salpha = sbuf + R * H;    // [R][64]
   __shared__ float s_score[R], s_lse[R], s_top[R];
   __shared__ int s_tok[R], s_done[R], s_src[R], s_nxt[R], s_fin[NB], s_exit;
@@ -211,7 +325,11 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
   const int b0 = blockIdx.x * NB;
   const int ju = 32 * wv + r32;    // hidden unit / output column owned in the MFMA phases
 
-  for (int i = tid; i < R * H; i += NT) sX[(i >> 8) * XS + H + (i & 255)] = 0.f;  // h = 0
+  if constexpr (SPLITW) {
+    for (int i = tid; i < 3 * PPL / 4; i += NT) lds[i] = 0.f;  // h = 0
+  } else {
+    for (int i = tid; i < R * H; i += NT) sX[(i >> 8) * XS + H + (i & 255)] = 0.f;
+  }
   f32x16 c;
 #pragma unroll
   for (int e = 0; e < 16; ++e) c[e] = 0.f;
@@ -232,7 +350,8 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
       const float bj = a.w.h2h_b[ju];
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = bj;
-      mfma_cols32(sX, H, a.w.h2h_wt, H, ju, true, r32, half, acc);
+      if constexpr (SPLITW) mfma_cols32_split(sP, a.h2h_p, H, ju, true, r32, half, acc);
+      else mfma_cols32(sX, H, a.w.h2h_wt, H, ju, true, r32, half, acc);
 #pragma unroll
       for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = acc[e];
     }
@@ -331,7 +450,7 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
         const int tk = s_tok[acc_row(e, half)];
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(&a.w.wih_tok[((long)tk * H + ju) * 4]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g][e] = b4[g] + t4[g];
+        for (int g = 0; g < 4; ++g) acc[g][e] = add_np(b4[g], t4[g]);
       }
       if constexpr (HOIST) {
         // + sum_t alpha[row][t] * P[crop(row)][t][ju][gate]; this lane's rows of crop nb are beams 4 * half + 0..3 = acc elements 4 nb + i
@@ -351,7 +470,7 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
                 for (int i = 0; i < 4; ++i) {
                   const float al = pa[i * 64 + t0 + u];
 #pragma unroll
-                  for (int g = 0; g < 4; ++g) acc[g][4 * nb + i] = fmaf(al, pv[u][g], acc[g][4 * nb + i]);
+                  for (int g = 0; g < 4; ++g) acc[g][4 * nb + i] = fmac_np(al, pv[u][g], acc[g][4 * nb + i]);
                 }
               }
           }
@@ -359,13 +478,30 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
       } else {
         mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
       }
-      mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
+      if constexpr (SPLITW) mfma_gates_split(sP, a.whh_p, ju, r32, half, acc);
+      else mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
       __syncthreads();  // every wave has read the old h
+      float hv[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float ig = sigmoidf_(acc[0][e]), fg = sigmoidf_(acc[1][e]), gg = ftanh(acc[2][e]), og = sigmoidf_(acc[3][e]);
         c[e] = fg * c[e] + ig * gg;
-        sX[acc_row(e, half) * XS + H + ju] = og * ftanh(c[e]);
+        hv[e] = og * ftanh(c[e]);
+      }
+      if constexpr (SPLITW) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {  // acc_row(e + 1) == acc_row(e) + 1
+          unsigned char* d = sP + acc_row(e, half) * PSB + ju * 2;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const uint32_t pk = split_pair(hv[e], hv[e + 1]);
+            *reinterpret_cast<uint16_t*>(d + pl * PPL) = (uint16_t)pk;
+            *reinterpret_cast<uint16_t*>(d + pl * PPL + PSB) = (uint16_t)(pk >> 16);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sX[acc_row(e, half) * XS + H + ju] = hv[e];
       }
     }
     __syncthreads();
@@ -377,7 +513,10 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
       const float bv = vok ? a.w.gen_b[ju] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = bv;
-      if (32 * wv < V) mfma_cols32(sX, H, a.w.gen_wt, V, ju, vok, r32, half, acc);
+      if (32 * wv < V) {
+        if constexpr (SPLITW) mfma_cols32_split(sP, a.gen_p, (V + 31) & ~31, ju, true, r32, half, acc);  // padded columns are zeros
+        else mfma_cols32(sX, H, a.w.gen_wt, V, ju, vok, r32, half, acc);
+      }
       if (vok) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -534,23 +673,45 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
     {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = c[e];
-      const int j = tid & 255, ch = tid >> 8;
-      float hn[R / 2];
+      if constexpr (SPLITW) {
+        const int j2 = tid & 127, nb = tid >> 7;  // column pair, crop: the crop's 8 rows of the three planes
+        uint32_t hp[3][KB8];
 #pragma unroll
-      for (int q = 0; q < R / 2; ++q) {
-        const int r = ch * (R / 2) + q, nb = r / KB8, rb = r % KB8;
-        const int src = rb < KB ? s_src[r] : rb;
-        hn[q] = sX[(nb * KB8 + src) * XS + H + j];
+        for (int rb = 0; rb < KB8; ++rb) {
+          const int src = rb < KB ? s_src[nb * KB8 + rb] : rb;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) hp[pl][rb] = *reinterpret_cast<const uint32_t*>(sP + pl * PPL + (nb * KB8 + src) * PSB + j2 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = acc_row(e, half), cb = r / KB8, rb = r % KB8;
+          const int src = rb < KB ? s_src[r] : rb;
+          c[e] = sbuf[(cb * KB8 + src) * H + ju];
+        }
+#pragma unroll
+        for (int rb = 0; rb < KB8; ++rb)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sP + pl * PPL + (nb * KB8 + rb) * PSB + j2 * 4) = hp[pl][rb];
+      } else {
+        const int j = tid & 255, ch = tid >> 8;
+        float hn[R / 2];
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+          const int r = ch * (R / 2) + q, nb = r / KB8, rb = r % KB8;
+          const int src = rb < KB ? s_src[r] : rb;
+          hn[q] = sX[(nb * KB8 + src) * XS + H + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = acc_row(e, half), nb = r / KB8, rb = r % KB8;
+          const int src = rb < KB ? s_src[r] : rb;
+          c[e] = sbuf[(nb * KB8 + src) * H + ju];
+        }
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) sX[(ch * (R / 2) + q) * XS + H + j] = hn[q];
       }
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = acc_row(e, half), nb = r / KB8, rb = r % KB8;
-        const int src = rb < KB ? s_src[r] : rb;
-        c[e] = sbuf[(nb * KB8 + src) * H + ju];
-      }
-#pragma unroll
-      for (int q = 0; q < R / 2; ++q) sX[(ch * (R / 2) + q) * XS + H + j] = hn[q];
     }
     __syncthreads();
     TSTAMP(10);
@@ -583,16 +744,49 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
 
 int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s) {
   const size_t ldsz = (size_t)(R * XS + R * H + R * 64) * sizeof(float);
+  const size_t ldsz_split = (size_t)3 * PPL + (size_t)(R * H + R * 64) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_beam_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz_split) != hipSuccess)
       return MSOCR_E_LAUNCH;
     attr = true;
   }
-  if (a.ctx_gates)
-    MSOCR_LAUNCH(attn_beam_mfma_kernel<true>, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
+  const dim3 grid((a.B + NB - 1) / NB);
+  if (a.ctx_gates && a.h2h_p)
+    MSOCR_LAUNCH((attn_beam_mfma_kernel<true, true>), grid, dim3(NT), ldsz_split, s, a);
+  else if (a.ctx_gates)
+    MSOCR_LAUNCH((attn_beam_mfma_kernel<true, false>), grid, dim3(NT), ldsz, s, a);
   else
-    MSOCR_LAUNCH(attn_beam_mfma_kernel<false>, dim3((a.B + NB - 1) / NB), dim3(NT), ldsz, s, a);
+    MSOCR_LAUNCH((attn_beam_mfma_kernel<false, false>), grid, dim3(NT), ldsz, s, a);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+// HOST helper: a transposed f32 weight matrix of the decoder ([256][N] row-major: h2h_wt, gen_wt; or gate-interleaved
+// [256][N / 4][4]: whh_t) -> the packed split form the matrix-core beam kernel reads: out[plane][k / 16][column][k % 16] bf16 with
+// w == p0 + p1 + p2 exactly; columns padded with zeros to a multiple of 32; gate-interleaved input: column = gate * (N / 4) + unit.
+extern "C" int64_t msocr_attn_pack_split_elems(int N) { return N > 0 ? (int64_t)3 * H * ((N + 31) & ~31) : 0; }
+extern "C" int msocr_attn_pack_split_host(const float* wt_host, int N, int gate_interleaved, uint16_t* out_host) {
+  if (!wt_host || !out_host || N <= 0 || (gate_interleaved && N % 4)) return MSOCR_E_ARG;
+  const int Np = (N + 31) & ~31;
+  const int64_t plane = (int64_t)H * Np;
+  for (int64_t i = 0; i < 3 * plane; ++i) out_host[i] = 0;
+  auto rne = [](float f) -> uint16_t {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  for (int k = 0; k < H; ++k)
+    for (int n = 0; n < N; ++n) {
+      const int col = gate_interleaved ? (n & 3) * (N / 4) + (n >> 2) : n;
+      float r = wt_host[(int64_t)k * N + n];
+      for (int pl = 0; pl < 3; ++pl) {
+        const uint16_t hb = rne(r);
+        out_host[pl * plane + ((int64_t)(k >> 4) * Np + col) * 16 + (k & 15)] = hb;
+        r -= __builtin_bit_cast(float, (uint32_t)hb << 16);
+      }
+    }
+  return MSOCR_OK;
 }

@@ -20,6 +20,7 @@ struct AttnArgs {
   const float* proj_H;
   const float* ctx_gates;  // optional (matrix-core beam kernel): [B][T][H][4] = batch_H x rnn.weight_ih[:, :H]^T, hoisted out of the step loop
   msocr_attn_weights w;
+  const uint16_t *h2h_p, *whh_p, *gen_p;  // optional (matrix-core beam kernel, with ctx_gates): msocr_attn_split_weights
   int B, T, V, steps, K;
   int sos_id, eos_id, blank_id;
   float temperature;

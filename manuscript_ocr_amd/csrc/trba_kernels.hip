@@ -715,8 +715,8 @@ extern "C" int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, i
   return beam_ws_logits(B, steps, beam, V) + (int64_t)B * steps * beam * 8 + (int64_t)B * steps * 4 + 256;
 }
 
-static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B, int T, int H,
-                          int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
+static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                          const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
                           int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
                           int32_t* chunk_state_dev, void* stream);
 
@@ -724,27 +724,31 @@ extern "C" int msocr_attn_beam(const float* batch_H, const float* proj_H, const 
                                int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
                                int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
                                int32_t* chunk_state_dev, void* stream) {
-  return attn_beam_impl(batch_H, proj_H, nullptr, w, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id, fin_step_out,
+  return attn_beam_impl(batch_H, proj_H, nullptr, w, nullptr, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id, fin_step_out,
                         workspace, chunk_id_dev, chunk_size_dev, chunk_state_dev, stream);
 }
 
 extern "C" int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
-                                       int B, int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id,
-                                       int eos_id, int blank_id, int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev,
-                                       const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream) {
+                                       const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int beam,
+                                       const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id, int32_t* fin_step_out,
+                                       void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
+                                       int32_t* chunk_state_dev, void* stream) {
   if (!ctx_gates || ((uintptr_t)ctx_gates & 15)) return MSOCR_E_ARG;
-  return attn_beam_impl(batch_H, proj_H, ctx_gates, w, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id, fin_step_out,
-                        workspace, chunk_id_dev, chunk_size_dev, chunk_state_dev, stream);
+  if (ws && (!ws->h2h_p || !ws->whh_p || !ws->gen_p || (((uintptr_t)ws->h2h_p | (uintptr_t)ws->whh_p | (uintptr_t)ws->gen_p) & 15)))
+    return MSOCR_E_ARG;
+  return attn_beam_impl(batch_H, proj_H, ctx_gates, w, ws, B, T, H, V, steps, beam, lp_dev, temperature, sos_id, eos_id, blank_id,
+                        fin_step_out, workspace, chunk_id_dev, chunk_size_dev, chunk_state_dev, stream);
 }
 
-static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w, int B, int T, int H,
-                          int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
+static int attn_beam_impl(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                          const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int beam, const float* lp_dev, float temperature, int sos_id, int eos_id, int blank_id,
                           int32_t* fin_step_out, void* workspace, const int32_t* chunk_id_dev, const int32_t* chunk_size_dev,
                           int32_t* chunk_state_dev, void* stream) {
   if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !fin_step_out || !workspace) return MSOCR_E_ARG;
   if (beam < 1 || beam > 16 || sos_id < 0 || sos_id >= V || ((uintptr_t)workspace & 15)) return MSOCR_E_ARG;
   AttnArgs a{};
   a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w; a.ctx_gates = ctx_gates;
+  if (ws) { a.h2h_p = ws->h2h_p; a.whh_p = ws->whh_p; a.gen_p = ws->gen_p; }
   a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = beam;
   a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = temperature; a.lp = lp_dev;
   char* p = (char*)workspace;

@@ -120,6 +120,17 @@ class TrbaNet:
         for k in ("h2h_wt", "h2h_b", "score_w", "wih_ctx_t", "wih_tok", "whh_t", "b_gates", "gen_wt", "gen_b"):
             setattr(aw, k, self.att[k].data_ptr())
         self._aw = aw
+        # split form of the three per-step matrices for the matrix-core beam kernel (precision "fp32"; "fp32-exact" keeps the f32 MFMA)
+        self._asw = None
+        if (ops.SPLIT_BF16X3 if split is None else split) and dtype == torch.float32 and H == 256 and self.V <= 256:
+            asw = nat.AttnSplitWeights()
+            for src, dst, n, gi in (("h2h_wt", "h2h_p", H, 0), ("whh_t", "whh_p", 4 * H, 1), ("gen_wt", "gen_p", self.V, 0)):
+                wt = self.att[src].cpu().contiguous()
+                packed = torch.empty((nat.lib().msocr_attn_pack_split_elems(n),), dtype=torch.int16)
+                nat.check(nat.lib().msocr_attn_pack_split_host(wt.data_ptr(), n, gi, packed.data_ptr()), "attn_pack_split_host")
+                self.att[dst] = packed.to(dev)
+                setattr(asw, dst, self.att[dst].data_ptr())
+            self._asw = asw
 
     # ------------------------------------------------------------------------------------- CNN
     def _se_block(self, x, lname, i, stride):
@@ -209,8 +220,9 @@ class TrbaNet:
                 chunks[0].data_ptr() if chunks else None, chunks[1].data_ptr() if chunks else None,
                 chunks[2].data_ptr() if chunks else None, ops._stream())
         if hoist:
-            nat.check(nat.lib().msocr_attn_beam_hoisted(batch_H.data_ptr(), proj_H.data_ptr(), ctxg.data_ptr(), ctypes.byref(self._aw), *tail),
-                      "attn_beam_hoisted")
+            asw = self._asw if os.environ.get("MSOCR_BEAM_SPLIT", "1") != "0" else None
+            nat.check(nat.lib().msocr_attn_beam_hoisted(batch_H.data_ptr(), proj_H.data_ptr(), ctxg.data_ptr(), ctypes.byref(self._aw),
+                                                        ctypes.byref(asw) if asw is not None else None, *tail), "attn_beam_hoisted")
         else:
             nat.check(nat.lib().msocr_attn_beam(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), *tail), "attn_beam")
         # SURVEY.md 8d, per decode step: proj_H + batch_H (shared by the beams) + LSTMCell W_ih (ctx part + one-hot rows), W_hh,

@@ -571,3 +571,28 @@ def test_bench_timed_region_world2_gloo(tmp_path):
     assert [x["page"] for x in res[0]["recs"]] == [0, 1, 2, 3] and res[0]["recs"][3]["text"] == "rank1-page1"
     assert json.loads(res[0]["line"])["n_gpus"] == 2 and res[1]["line"] == ""
     assert res[0]["shard"] == [0, 4] and res[1]["shard"] == [4, 7]
+
+
+def test_attn_pack_split_host_layout_and_exactness():
+    """msocr_attn_pack_split_host: planes sum to the f32 weight exactly; layout [plane][k/16][column][k%16], columns padded to 32,
+    gate-interleaved input reordered gate-major."""
+    import torch
+    from manuscript_ocr_amd import _native as nat
+    L = nat.lib()
+    torch.manual_seed(3)
+    for N, gi in ((256, 0), (1024, 1), (194, 0)):
+        wt = (torch.randn(256, N) * 0.1).contiguous()
+        Np = (N + 31) // 32 * 32
+        assert L.msocr_attn_pack_split_elems(N) == 3 * 256 * Np
+        out = torch.full((3 * 256 * Np,), -1, dtype=torch.int16)
+        assert L.msocr_attn_pack_split_host(wt.data_ptr(), N, gi, out.data_ptr()) == 0
+        f = ((out.view(3, 16, Np, 16).to(torch.int32) & 0xffff) << 16).view(torch.float32).double()
+        rec = (f[0] + f[1] + f[2]).permute(0, 2, 1).reshape(256, Np)
+        if gi:
+            rec = rec.view(256, 4, N // 4).permute(0, 2, 1).reshape(256, N)
+        else:
+            assert float(rec[:, N:].abs().max()) == 0.0 if Np > N else True
+            rec = rec[:, :N]
+        assert torch.equal(rec, wt.double())
+    assert L.msocr_attn_pack_split_host(None, 256, 0, out.data_ptr()) != 0
+    assert L.msocr_attn_pack_split_host(wt.data_ptr(), 6, 1, out.data_ptr()) != 0
