@@ -147,8 +147,14 @@ class EastNet:
                     w, b = conv_bn(p + f"conv{j}", p + f"bn{j}")
                     P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
                 if i == 0:
-                    w, b = conv_bn(p + "downsample.0", p + "downsample.1")
-                    P[f"{lname}.{i}.down"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
+                    wd, bd = conv_bn(p + "downsample.0", p + "downsample.1")
+                    P[f"{lname}.{i}.down"] = (to_khwc(wd, dtype, self.device, split), bd.to(self.device))
+                    if stride == 1:
+                        # conv3 and the stride-1 downsample of the layer's first block read the same pixels: one GEMM over the
+                        # channel concatenation [conv2 output | block input] with [W3 | Wd] (K = planes + Cin) replaces two
+                        # launches, the downsample's output round trip through HBM and the residual read (torchvision Bottleneck:
+                        # out = relu(bn3(conv3(.)) + downsample(x)))
+                        P[f"{lname}.{i}.conv3d"] = (to_khwc(torch.cat([w, wd], dim=1), dtype, self.device, split), (b + bd).to(self.device))
         for k in (1, 2, 3, 4):
             p = f"decoder.block{k}."
             w, b = conv_bn(p + "conv1x1.0", p + "conv1x1.1", p + "conv1x1.0.bias")
@@ -161,12 +167,17 @@ class EastNet:
         self.P = P
 
     # -------------------------------------------------------------------------------------
-    def _bottleneck(self, x, lname, i, stride, out=None):
+    def _bottleneck(self, x, lname, i, stride, out=None, yx=None):
+        """yx (first block of layer1 only): [N,h,w,planes+Cin] buffer whose last Cin channels ARE x; conv2 writes beside them."""
         P = self.P
         w1, b1 = P[f"{lname}.{i}.conv1"]
         w2, b2 = P[f"{lname}.{i}.conv2"]
         w3, b3 = P[f"{lname}.{i}.conv3"]
         o1 = ops.conv2d(x, w1, b1, relu=True)
+        if yx is not None:
+            w3d, b3d = P[f"{lname}.{i}.conv3d"]
+            ops.conv2d(o1, w2, b2, pad=(1, 1), relu=True, out=yx[..., : w2.shape[0]])
+            return ops.conv2d(yx, w3d, b3d, relu=True, out=out)
         o2 = ops.conv2d(o1, w2, b2, stride=(stride, stride), pad=(1, 1), relu=True)
         if i == 0:
             wd, bd = P[f"{lname}.{i}.down"]
@@ -186,14 +197,17 @@ class EastNet:
         ws, bs = self.P["stem"]
         x = ops.conv2d(stem_view(canvas, 32, 7), ws, bs, (2, 2), (0, 0), True, out_hw=(H // 2, W // 2), alg_k=147)
         del canvas
-        x = ops.maxpool2d(x, 3, 2, 1)
+        yx = torch.empty((N, H // 4, W // 4, 128), dtype=dt, device=dev)  # layer1.0: [conv2 output | block input], see conv3d
+        x = ops.maxpool2d(x, 3, 2, 1, out=yx[..., 64:])
         cat1 = torch.empty((N, H // 4, W // 4, 128 + 256), dtype=dt, device=dev)
         cat2 = torch.empty((N, H // 8, W // 8, 256 + 512), dtype=dt, device=dev)
         cat3 = torch.empty((N, H // 16, W // 16, 512 + 1024), dtype=dt, device=dev)
         taps = {"layer1": cat1[..., 128:], "layer2": cat2[..., 256:], "layer3": cat3[..., 512:], "layer4": None}
         for lname, planes, blocks, stride in LAYERS:
             for i in range(blocks):
-                x = self._bottleneck(x, lname, i, stride if i == 0 else 1, out=taps[lname] if i == blocks - 1 else None)
+                x = self._bottleneck(x, lname, i, stride if i == 0 else 1, out=taps[lname] if i == blocks - 1 else None,
+                                     yx=yx if (lname == "layer1" and i == 0) else None)
+            yx = None
         P = self.P
 
         def dec(k, t):

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 B=${1:-1024}
 cd $R/manuscript_ocr_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -DMSOCR_ATTN_TIMING -shared \
-  attn_beam_mfma.hip trba_kernels.hip -o /tmp/libattn_timing.so
+  attn_beam_mfma.hip trba_kernels.hip attn_general.hip -o /tmp/libattn_timing.so
 cd $R
 python3 - <<PY
 import ctypes, sys, numpy as np, torch
