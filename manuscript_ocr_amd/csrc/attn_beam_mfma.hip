@@ -127,8 +127,12 @@ __device__ __forceinline__ float add_np(float a, float b) {
   return r;
 }
 __device__ __forceinline__ float fmac_np(float a, float b, float c) {
+#ifdef MSOCR_ATTN_PACKED_SUM  // dev builds (tools/attn_packed_probe.sh): the form the compiler pairs into v_pk_fma_f32
+  return fmaf(a, b, c);
+#else
   asm("v_fmac_f32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
   return c;
+#endif
 }
 
 // row of accumulator register e in the 32x32 MFMA output layout (lane half = lane >> 5)
@@ -475,6 +479,9 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
               }
           }
         }
+#ifdef MSOCR_ATTN_SUM_BARRIER  // dev builds: no wave enters the MFMA loop while another is still in the sum above
+        __syncthreads();
+#endif
       } else {
         mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
       }
