@@ -206,6 +206,11 @@ int msocr_mean_over_h(const void* in, int N, int H, int W, int C, int dtype, flo
  * hcat_out [B][T][2H] f32. */
 int msocr_bilstm_recurrent(const float* xproj, const float* w_hh_t, int B, int T, int H, float* hcat_out,
                            void* stream);
+/* The same recurrence (H == 256) with the step's product h W_hh^T on the bf16 matrix pipes in the split-operand form, 32 crops per
+ * workgroup (csrc/bilstm_mfma.hip).  whh_planes (device): two blocks (forward, reverse) of msocr_attn_pack_split_elems(4 H)
+ * uint16 each, packed on the host by msocr_attn_pack_split_host(w_hh_t + dir * H * 4 H, 4 H, 1, .). */
+int msocr_bilstm_recurrent_split(const float* xproj, const uint16_t* whh_planes, int B, int T, int H, float* hcat_out,
+                                 void* stream);
 
 typedef struct msocr_attn_weights {
   const float* h2h_wt;   /* [H][H]   h2h.weight^T */

@@ -79,6 +79,7 @@ _SIGS = {
     "msocr_se_residual": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_mean_over_h": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_bilstm_recurrent": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "msocr_bilstm_recurrent_split": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_attn_greedy": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_vp, c_vp, c_vp]),
     "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,

@@ -500,13 +500,19 @@ def mean_over_h(x):
     return out
 
 
-def bilstm_recurrent(xproj, whh_t, B, T, H):
-    """xproj [B*T, 2*4H] f32 (= [B][T][2][4H]), whh_t [2,H,H,4] f32 (gate-interleaved) -> hcat [B,T,2H] f32."""
+def bilstm_recurrent(xproj, whh_t, B, T, H, whh_planes=None):
+    """xproj [B*T, 2*4H] f32 (= [B][T][2][4H]), whh_t [2,H,H,4] f32 (gate-interleaved) -> hcat [B,T,2H] f32.
+    whh_planes (H == 256): W_hh of both directions in the packed split form -> the matrix-core kernel (csrc/bilstm_mfma.hip)."""
     _need_cuda(xproj, whh_t)
     assert xproj.is_contiguous() and xproj.numel() == B * T * 8 * H and whh_t.shape == (2, H, H, 4) and whh_t.is_contiguous()
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=xproj.device)
     e = _prof_begin()
-    nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
+    if (whh_planes is not None and H == 256 and SPLIT_BF16X3 and B * T * 8 * H < 2 ** 32
+            and os.environ.get("MSOCR_BILSTM_MFMA", "1") != "0"):
+        nat.check(nat.lib().msocr_bilstm_recurrent_split(xproj.data_ptr(), whh_planes.data_ptr(), B, T, H, out.data_ptr(), _stream()),
+                  "bilstm_recurrent_split")
+    else:
+        nat.check(nat.lib().msocr_bilstm_recurrent(xproj.data_ptr(), whh_t.data_ptr(), B, T, H, out.data_ptr(), _stream()), "bilstm_recurrent")
     # SURVEY.md 8d: per step per direction W_hh (4H x H f32) + B * (h + c + 4H pre-gates) * 4 B * 2
     _prof_end(e, "bilstm", (2.0 * T * (4.0 * H * H * 4 + B * (H + H + 4 * H) * 4 * 2), T), (B, T, H))
     return out

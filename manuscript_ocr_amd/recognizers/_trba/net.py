@@ -91,9 +91,18 @@ class TrbaNet:
                            sd[p + "rnn.bias_ih_l0_reverse"] + sd[p + "rnn.bias_hh_l0_reverse"]]).float()
             whh_t = torch.stack([_gate_interleave(sd[p + "rnn.weight_hh_l0"].float().t(), H),
                                  _gate_interleave(sd[p + "rnn.weight_hh_l0_reverse"].float().t(), H)])  # [2][H(k)][H(j)][4]
+            whh_p = None
+            if (ops.SPLIT_BF16X3 if split is None else split) and dtype == torch.float32 and H == 256:
+                # W_hh of both directions in the packed split form of the matrix-core recurrence (csrc/bilstm_mfma.hip)
+                n = nat.lib().msocr_attn_pack_split_elems(4 * H)
+                packed = torch.empty((2, n), dtype=torch.int16)
+                wt = whh_t.contiguous()
+                for d in (0, 1):
+                    nat.check(nat.lib().msocr_attn_pack_split_host(wt[d].data_ptr(), 4 * H, 1, packed[d].data_ptr()), "attn_pack_split_host")
+                whh_p = packed.to(dev)
             self.rnn.append({
                 "w_ih": w_ih.view(8 * H, 1, 1, -1).contiguous().to(dev), "b": b.contiguous().to(dev),
-                "whh_t": whh_t.contiguous().to(dev),
+                "whh_t": whh_t.contiguous().to(dev), "whh_p": whh_p,
                 "lin_w": sd[p + "linear.weight"].float().view(H, 1, 1, 2 * H).contiguous().to(dev),
                 "lin_b": sd[p + "linear.bias"].float().contiguous().to(dev),
             })
@@ -172,7 +181,7 @@ class TrbaNet:
         for l in (0, 1):
             r = self.rnn[l]
             xproj = self._gemm(seq.view(B * T, -1), r["w_ih"], r["b"])  # [B*T, 2*4H] = [B][T][2][4H]
-            hcat = ops.bilstm_recurrent(xproj, r["whh_t"], B, T, H)   # [B,T,2H]
+            hcat = ops.bilstm_recurrent(xproj, r["whh_t"], B, T, H, r["whh_p"])   # [B,T,2H]
             seq = self._gemm(hcat.view(B * T, 2 * H), r["lin_w"], r["lin_b"]).view(B, T, H)
         proj = self._gemm(seq.view(B * T, H), self.att["i2h_w"], None).view(B, T, H)
         return seq, proj

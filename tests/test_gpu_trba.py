@@ -64,6 +64,22 @@ def test_se_residual_and_bilstm_ops(env):
         whh_t = torch.stack([il(sd["weight_hh_l0"]), il(sd["weight_hh_l0_reverse"])])
     got = ops.bilstm_recurrent(xproj.cuda(), whh_t.cuda(), B, T, H).cpu()
     assert (got - ref_h).abs().max().item() < 2e-5
+    # the matrix-core recurrence (csrc/bilstm_mfma.hip: 32 crops per workgroup, h W_hh^T in the split-operand form), same bound;
+    # 70 crops = two full row blocks + a ragged one
+    from manuscript_ocr_amd import _native as nat
+    B2 = 70
+    xs2 = torch.randn(B2, T, In, generator=g) * 2.0
+    with torch.no_grad():
+        ref2, _ = lstm(xs2)
+        xproj2 = (xs2.reshape(B2 * T, In) @ w_ih.t() + bias).contiguous()
+    n = nat.lib().msocr_attn_pack_split_elems(4 * H)
+    packed = torch.empty((2, n), dtype=torch.int16)
+    for d in (0, 1):
+        assert nat.lib().msocr_attn_pack_split_host(whh_t[d].contiguous().data_ptr(), 4 * H, 1, packed[d].data_ptr()) == 0
+    got2 = ops.bilstm_recurrent(xproj2.cuda(), whh_t.cuda(), B2, T, H, packed.cuda()).cpu()
+    valu = ops.bilstm_recurrent(xproj2.cuda(), whh_t.cuda(), B2, T, H).cpu()
+    assert (valu - ref2).abs().max().item() < 2e-5
+    assert (got2 - ref2).abs().max().item() < 2e-5, (got2 - ref2).abs().max().item()
 
 
 @pytest.mark.parametrize("tag,B,h,w", [("b4_32x100", 4, 32, 100), ("b2_64x256", 2, 64, 256)])
