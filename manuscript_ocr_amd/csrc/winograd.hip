@@ -644,6 +644,177 @@ __global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __r
   }
 }
 
+// ---- fused Cin = 64 layer, second form (round 3, split operands, Cout % 64 == 0) --------------------------------------------------
+// The kernel above holds the 24 products of a (tile, cout) pair in 24 accumulators and transforms them at the end, which pins a
+// wave to one 16 x 16 block (96 accumulator registers) and a workgroup to 32 tiles x 32 couts: per point 12 short MFMAs between two
+// barriers, and every workgroup pulls all of U for its 32 couts (288 KB) from L2 for 32 tiles (PMC: matrix pipes 0.25 busy on conv0b,
+// 13 ms per step).  The output transform is linear in the 24 products, so this form accumulates it on the fly:
+//   Y[a][b] += AT6[a][i] * AT4[b][j] * M[i][j]   right after point (i, j) is multiplied
+// (8 output accumulators + the current product; 108 FMAs per element and kernel instead of 24 x 64 MACs on the pipes).  A wave then
+// owns a 32 x 32 block (v_mfma_f32_32x32x16_bf16, 24 per point), a workgroup 64 tiles x 64 couts: 4x the matrix work per barrier and
+// half the L2 traffic per MAC.  Same V / U layouts, same epilogue semantics (bias, residual, ReLU, MaxPool2d(2, 2)).
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void wino42_fused64_v2_kernel(const float* __restrict__ V, const unsigned short* __restrict__ U, int Cout,
+                                                                    WinoGeom g, const float* __restrict__ bias,
+                                                                    const float* __restrict__ res, long res_ld, int relu,
+                                                                    float* __restrict__ out, long out_ld) {
+  constexpr int K = 64, BM = 64, BN = 64, ROWS = 128, PLANE = BM * ROWS;  // six [64 rows][64 bf16 = 128 B] planes, one stage
+  typedef float f32x16w __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int nbn = Cout / BN;
+  const long nblk = (long)gridDim.x;
+  long bid = blockIdx.x;
+  {  // XCD-aware order, cout blocks fastest (the workgroups that read one V tile share an L2)
+    const long q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int nb = (int)(bid % nbn);
+  const long m0 = (bid / nbn) * BM;
+  const int n0 = nb * BN;
+
+  // staging: V rows = tid / 16 + 16 i, 16-B chunk of 4 f32 = tid % 16; U planes: rows = tid / 8 + 32 j, 16-B chunk of 8 bf16 = tid % 8
+  const int chunk = tid & 15, row0 = tid >> 4;
+  const int bchunk = tid & 7, brow = tid >> 3;
+  const long planeV = g.Mt * (long)K, planeU = (long)Cout * K, uplane = 24 * planeU;
+  const float* pa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long m = m0 + row0 + 16 * i;
+    if (m >= g.Mt) m = g.Mt - 1;  // valid memory; the rows are never stored
+    pa[i] = V + m * K + chunk * 4;
+  }
+  const unsigned short* pb = U + (long)(n0 + brow) * K + bchunk * 8;
+  u32x4w ra[4], rb[3][2];
+  auto gload = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4w*>(pa[i] + p * planeV);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb[pl][j] = *reinterpret_cast<const u32x4w*>(pb + pl * uplane + p * planeU + (long)j * 32 * K);
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + 16 * i;
+      float x0 = __uint_as_float(ra[i][0]), x1 = __uint_as_float(ra[i][1]), x2 = __uint_as_float(ra[i][2]), x3 = __uint_as_float(ra[i][3]);
+      unsigned char* dst = smem + row * ROWS + (((chunk >> 1) ^ (row & 7)) << 4) + ((chunk & 1) << 3);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x2w v;
+        v[0] = wino_split_step(x0, x1);
+        v[1] = wino_split_step(x2, x3);
+        *reinterpret_cast<u32x2w*>(dst + pl * PLANE) = v;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = brow + 32 * j;
+        *reinterpret_cast<u32x4w*>(smem + (3 + pl) * PLANE + row * ROWS + ((bchunk ^ (row & 7)) << 4)) = rb[pl][j];
+      }
+  };
+
+  f32x16w Y[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Y[o][e] = 0.f;
+
+  gload(0);
+  sstore();
+  __syncthreads();
+  // coefficient of point p = 4 i + j in output o = 2 a + b: AT6[a][i] * AT4[b][j], AT6 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],
+  // [0,1,-1,8,-8,1]], AT4 = [[1,1,1,0],[0,1,-1,-1]] — a run-time table and a ROLLED loop over the points: unrolled, the 24 points'
+  // loads and products are hoisted across each other and the kernel spills (375 registers fully unrolled, 128 with four points
+  // per iteration); the price is 8 FMAs per element and point including the 84 zero coefficients (192 instead of 108)
+  __shared__ float s_cf[24][8];
+  if (tid < 192) {
+    const float t6[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    const float t4[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+    const int pp = tid >> 3, o = tid & 7;
+    s_cf[pp][o] = t6[o >> 1][pp >> 2] * t4[o & 1][pp & 3];
+  }
+  __syncthreads();
+  const int rowa = wm * 32 + r32, rowb = wn * 32 + r32;
+#pragma unroll 1
+  for (int p = 0; p < 24; ++p) {
+    if (p + 1 < 24) gload(p + 1);  // in flight under this point's MFMAs
+    f32x16w m;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // k16 steps; lane (r32, half) takes k = 16 ks + 8 half + 0..7 of its row for both operands
+      const int c = 2 * ks + half;
+      bf16x8w fa[3], fb[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        fa[pl] = *reinterpret_cast<const bf16x8w*>(smem + pl * PLANE + rowa * ROWS + ((c ^ (rowa & 7)) << 4));
+        fb[pl] = *reinterpret_cast<const bf16x8w*>(smem + (3 + pl) * PLANE + rowb * ROWS + ((c ^ (rowb & 7)) << 4));
+      }
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], m, 0, 0, 0);  // smallest terms first
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], m, 0, 0, 0);
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], m, 0, 0, 0);
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], m, 0, 0, 0);
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], m, 0, 0, 0);
+      m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], m, 0, 0, 0);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const float cf = s_cf[p][o];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Y[o][e] = fmaf(cf, m[e], Y[o][e]);
+    }
+    __syncthreads();  // every wave has read the stage
+    if (p + 1 < 24) sstore();
+    __syncthreads();
+  }
+
+  // ---- epilogue: element e of this lane = tile m0 + 32 wm + (e & 3) + 8 (e >> 2) + 4 half, cout n0 + 32 wn + r32 ----
+  const int co = n0 + wn * 32 + r32;
+  const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long t = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    if (t >= g.Mt) continue;
+    const int tw = (int)(t % g.TW);
+    const long r = t / g.TW;
+    const int th = (int)(r % g.TH);
+    const int n = (int)(r / g.TH);
+    if constexpr (POOL) {
+      const int Hp = g.H >> 1, Wp = g.W >> 1;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int hp = 2 * th + i2;
+        if (hp >= Hp || tw >= Wp) continue;
+        float v0 = Y[4 * i2 + 0][e] + bv, v1 = Y[4 * i2 + 1][e] + bv, v2 = Y[4 * i2 + 2][e] + bv, v3 = Y[4 * i2 + 3][e] + bv;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        out[(((long)n * Hp + hp) * Wp + tw) * out_ld + co] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int ho = 4 * th + a;
+        if (ho >= g.H) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int wo = 2 * tw + b;
+          if (wo >= g.W) continue;
+          const long pix = ((long)n * g.H + ho) * g.W + wo;
+          float v = Y[a * 2 + b][e] + bv;
+          if (res) v += res[pix * res_ld + co];
+          if (relu) v = fmaxf(v, 0.f);
+          out[pix * out_ld + co] = v;
+        }
+      }
+    }
+  }
+}
+
 static int wino42_fused_check(const msocr_conv_desc* d, WinoGeom* g) {
   if (!wino42_geom(d, g) || d->Cin != 64) return MSOCR_E_ARG;
   if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
@@ -689,6 +860,19 @@ static int wino42_fused_launch(const msocr_conv_desc* d, const void* u_weight, b
   const dim3 grid((unsigned)nblk), blk(256);
   hipStream_t st = (hipStream_t)stream;
   const float* ws = (const float*)workspace;
+  // split operands and Cout % 64 == 0: the on-the-fly output transform with 64 x 64 workgroup tiles (MSOCR_WINO_FUSED_V2=0: the
+  // 24-accumulator kernel, kept for Cout % 64 != 0 and as the cross-check of the tests)
+  static const bool v2 = !(getenv("MSOCR_WINO_FUSED_V2") && getenv("MSOCR_WINO_FUSED_V2")[0] == '0');
+  if (split && v2 && d->Cout % 64 == 0) {
+    const long nblk2 = ((g.Mt + 63) / 64) * (long)(d->Cout / 64);
+    const dim3 grid2((unsigned)nblk2);
+    const unsigned short* up = (const unsigned short*)u_weight;
+    if (d->flags & MSOCR_CONV_POOL2)
+      MSOCR_LAUNCH((wino42_fused64_v2_kernel<true>), grid2, blk, 0, st, ws, up, d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
+    else
+      MSOCR_LAUNCH((wino42_fused64_v2_kernel<false>), grid2, blk, 0, st, ws, up, d->Cout, g, bias, rp, (long)d->res_ld, relu, (float*)out, (long)d->out_ld);
+    return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+  }
   if (d->flags & MSOCR_CONV_POOL2) {
     if (split) MSOCR_LAUNCH((wino42_fused64_kernel<true, true>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);
     else MSOCR_LAUNCH((wino42_fused64_kernel<true, false>), grid, blk, 0, st, ws, u_weight, d->Cout, g, bias, (const float*)nullptr, 0L, relu, (float*)out, (long)d->out_ld);

@@ -160,7 +160,8 @@ def attach_winograd(w, split=None):
         w._msocr_wino42_fused = u42.to(w.device)
         # the K = 64 GEMMs on the bf16 pipes pay only for the wide layer (TRBA conv0b, 64 -> 128 + pool: 2.43 -> 2.21 ms per 960 crops);
         # with 64 output channels the kernel is bound by staging and barriers either way (0.84 -> 0.86 ms) and stays exact
-        if (SPLIT_BF16X3 if split is None else split) and Cout >= 128:
+        v2 = os.environ.get("MSOCR_WINO_FUSED_V2", "1") != "0"  # wino42_fused64_v2_kernel (Cout % 64 == 0)
+        if (SPLIT_BF16X3 if split is None else split) and ((v2 and Cout % 64 == 0) or Cout >= 128):
             w._msocr_wino42_fused_split = split_planes(u42).to(w.device)  # [3][24][Cout][64] bf16
         return w
     if not (WINOGRAD_MIN_CIN and w.dtype == torch.float32 and KH == 3 and KW == 3 and Cin >= WINOGRAD_MIN_CIN and Cin % 16 == 0
