@@ -68,7 +68,12 @@ def parse():
 
 
 CONV_STAGE_KERNELS = ("conv_igemm_kernel", "conv_split_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel",
-                      "wino42_fused64_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+                      "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+
+
+def _bf16_mfma_kernel(n):
+    """Kernels whose MFMAs are the bf16 ones of the split-operand form (1024 FLOP per busy cycle and SIMD, 6 per f32-equivalent FLOP)."""
+    return n.startswith(("conv_split_kernel", "wino42_fused64_v2_kernel")) or (n.startswith("wino42_fused64_kernel") and n.rstrip(">").endswith("true"))
 
 
 def live_pmc_traffic(a):
@@ -153,13 +158,13 @@ def live_pmc_traffic(a):
             ns = sum(v[2] for n, v in mf.items() if pred(n))
             # FLOP per busy cycle of one SIMD's matrix pipe: exact-f32 MFMA 64; v_mfma_f32_32x32x16_bf16 1024 (32768 FLOP in 32 cycles),
             # of which a split launch needs 6 per f32-equivalent FLOP
-            pipe = sum(v[0] * (1024.0 if n.startswith("conv_split_kernel") else 64.0) for n, v in mf.items() if pred(n))
-            equiv = sum(v[0] * (1024.0 / 6.0 if n.startswith("conv_split_kernel") else 64.0) for n, v in mf.items() if pred(n))
+            pipe = sum(v[0] * (1024.0 if _bf16_mfma_kernel(n) else 64.0) for n, v in mf.items() if pred(n))
+            equiv = sum(v[0] * (1024.0 / 6.0 if _bf16_mfma_kernel(n) else 64.0) for n, v in mf.items() if pred(n))
             return {"mfma_pipe_busy_fraction": b / (g / 8.0 * 1024.0), "clock_ghz": g / 8.0 / ns,
                     "executed_mfma_tflops": pipe / (ns * 1e-9) / 1e12, "f32_equivalent_tflops": equiv / (ns * 1e-9) / 1e12,
                     "kernel_ms_per_step": ns / steps / 1e6} if g > 0 else None
         mfma = {"conv_stage": util(lambda n: True),
-                "gemm_kernels": util(lambda n: n.startswith(("conv_igemm_kernel", "conv_split_kernel", "wino42_fused64_kernel", "wino_gemm4_kernel"))),
+                "gemm_kernels": util(lambda n: n.startswith(("conv_igemm_kernel", "conv_split_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel"))),
                 "split_gemm_kernel": util(lambda n: n.startswith("conv_split_kernel")),
                 "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 x 1024 SIMDs), one rocprofv3 --pmc "
                             "pass with --serialize-streams; conv_stage = GEMM kernels + Winograd transforms, gemm_kernels = without them"}
