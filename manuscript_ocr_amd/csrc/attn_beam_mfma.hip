@@ -372,8 +372,8 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g][e] = add_np(b4[g], t4[g]);
       }
-      if constexpr (HOIST) {
-        // + sum_t alpha[row][t] * P[crop(row)][t][ju][gate]; this lane's rows of crop nb are beams 4 * half + 0..3 = acc elements 4 nb + i
+      // + sum_t alpha[row][t] * P[crop(row)][t][ju][gate]; this lane's rows of crop nb are beams 4 * half + 0..3 = acc elements 4 nb + i
+      auto ctx_sum = [&]() {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float* pP = a.ctx_gates + ((long)min(b0 + nb, a.B - 1) * T * H + ju) * 4;
@@ -395,14 +395,32 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
               }
           }
         }
-#ifdef MSOCR_ATTN_SUM_BARRIER  // dev builds: no wave enters the MFMA loop while another is still in the sum above
-        __syncthreads();
+      };
+#if defined(MSOCR_ATTN_SUM_BARRIER) || defined(MSOCR_ATTN_NO_STAGGER)
+      constexpr bool STAGGER = false;
+#else
+      constexpr bool STAGGER = HOIST && SPLITW;
 #endif
+      if constexpr (STAGGER) {
+        // The context sum is load-latency and VALU work, the recurrent product matrix-pipe work, and the two are independent: the two
+        // waves of a SIMD (w and w + 4) take them in opposite orders, so one's loads and FMAs run under the other's MFMAs instead of
+        // both waiting for memory and then both queueing on the pipe (one-register FMAs: see add_np / fmac_np above).
+        const bool mfma_first = __builtin_amdgcn_readfirstlane(wv) >= 4;
+        if (!mfma_first) ctx_sum();
+        mfma_gates_split(sP, a.whh_p, ju, r32, half, acc);
+        if (mfma_first) ctx_sum();
       } else {
-        mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+        if constexpr (HOIST) {
+          ctx_sum();
+#ifdef MSOCR_ATTN_SUM_BARRIER  // dev builds: no wave enters the MFMA loop while another is still in the sum above
+          __syncthreads();
+#endif
+        } else {
+          mfma_gates(sX, 0, a.w.wih_ctx_t, ju, r32, half, acc);
+        }
+        if constexpr (SPLITW) mfma_gates_split(sP, a.whh_p, ju, r32, half, acc);
+        else mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
       }
-      if constexpr (SPLITW) mfma_gates_split(sP, a.whh_p, ju, r32, half, acc);
-      else mfma_gates(sX, H, a.w.whh_t, ju, r32, half, acc);
       __syncthreads();  // every wave has read the old h
       float hv[16];
 #pragma unroll
