@@ -596,3 +596,31 @@ def test_attn_pack_split_host_layout_and_exactness():
         assert torch.equal(rec, wt.double())
     assert L.msocr_attn_pack_split_host(None, 256, 0, out.data_ptr()) != 0
     assert L.msocr_attn_pack_split_host(wt.data_ptr(), 6, 1, out.data_ptr()) != 0
+
+
+def test_built_library_has_no_cross_dword_packed_f32_instruction(tmp_path):
+    """The gfx950 code objects inside libmsocr.so hold no packed-f32 VALU instruction whose LOW result takes the HIGH dword of a
+    source pair (`v_pk_*_f32 ... op_sel:[..]`): that form returned wrong lanes beside bf16 MFMAs on MI355X (csrc/Makefile,
+    DESIGN.md section 4, profiles/r03_attn_packed_probe.txt), so the kernels that had it are compiled without packed-f32 ops.
+    This looks at the artifact the tests and the bench actually load."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "manuscript_ocr_amd", "libmsocr.so")
+    if not os.path.exists(objdump) or not os.path.exists(lib):
+        pytest.skip("llvm-objdump or the built library is missing")
+    shutil.copy(lib, tmp_path / "libmsocr.so")
+    subprocess.run([objdump, "--offloading", "libmsocr.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert objs, "no gfx950 code object found in libmsocr.so"
+    packed, bad = 0, []
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for line in asm.splitlines():
+            if re.search(r"\bv_pk_[a-z]+_f32\b", line):
+                packed += 1
+                if "op_sel:[" in line:
+                    bad.append(line.strip())
+    assert not bad, f"{len(bad)} cross-dword packed-f32 instructions, e.g. {bad[:3]}"
+    assert packed > 0  # conv_split / conv_igemm keep their same-dword packed forms: the scan really saw device code
