@@ -74,13 +74,13 @@ __device__ __forceinline__ void st4<uint16_t>(uint16_t* p, f32x4 v) {
 
 // Measured and dropped (round 3): keeping the summed x values of a 4 x 13 map in registers (26 x 16 B per thread) so that the scale
 // pass does not read x again — 0.118 against 0.091 ms per 960 crops: the second read hits L2, and 163 registers cost occupancy.
-template <typename T>
-__global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ x, const T* __restrict__ idt, int HW, int C,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void se_residual_kernel(const T* __restrict__ x, const T* __restrict__ idt, int HW, int C,
                                                            const float* __restrict__ w1, const float* __restrict__ w2,
                                                            float* __restrict__ gate_ws, T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // part[PG][C] | mean[C] | hid[C/16] | gate[C]
   const int n = blockIdx.x, tid = threadIdx.x;
-  const int C4 = C / 4, PG = 256 / C4;  // host guarantees C in {64,128,256,512,1024}: C4 divides 256
+  const int C4 = C / 4, PG = NT / C4;  // host guarantees C in {64,128,256,512,1024}: C4 divides NT
   float* part = sm;
   float* mean = sm + PG * C;
   float* hid = mean + C;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ 
   }
   __syncthreads();
   const float inv = 1.0f / (float)HW;
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     float s = 0.f;
     for (int g = 0; g < PG; ++g) s += part[g * C + c];
     mean[c] = s * inv;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ 
   const int Cr = C / 16;
   {  // hid = relu(W1 mean): one wave per output, lanes over C
     const int lane = tid & 63, wv = tid >> 6;
-    for (int j = wv; j < Cr; j += 4) {
+    for (int j = wv; j < Cr; j += NT / 64) {
       float a = 0.f;
       for (int c = lane; c < C; c += 64) a = fmaf(w1[(long)j * C + c], mean[c], a);
       a = wave_sum(a);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ 
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     float a = 0.f;
     for (int j = 0; j < Cr; ++j) a = fmaf(w2[(long)c * Cr + j], hid[j], a);
     const float g = sigmoidf_(a);
@@ -165,16 +165,26 @@ __global__ __launch_bounds__(256) void se_residual_kernel(const T* __restrict__ 
 extern "C" int msocr_se_residual(const void* x, const void* identity, int N, int HW, int C, int dtype, const float* w1, const float* w2,
                                  float* gate_ws, void* out, void* stream) {
   if (!x || !identity || !w1 || !w2 || !gate_ws || !out || N <= 0 || HW <= 0 || C < 64 || C > 1024 || (C & (C - 1))) return MSOCR_E_ARG;
-  const size_t lds = (size_t)((1024 / C) * C + 2 * C + C / 16) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MSOCR_F32)
-    MSOCR_LAUNCH(se_residual_kernel<float>, dim3(N), dim3(256), lds, s, (const float*)x, (const float*)identity, HW, C, w1, w2, gate_ws,
-                 (float*)out);
-  else if (dtype == MSOCR_BF16)
-    MSOCR_LAUNCH(se_residual_kernel<uint16_t>, dim3(N), dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)identity, HW, C, w1, w2,
-                 gate_ws, (uint16_t*)out);
-  else
+  // f32: 1024-thread workgroups (2 per CU: 512 crops in flight).  A crop is read twice (mean, then scale); with 256-thread workgroups
+  // all 1920 crops of a sub-batch are resident at once — 0.8 GB between the two reads of a crop, nothing of it left in L2 / MALL.
+  // Measured per 1920 crops: 0.587 / 0.311 / 0.173 ms (16x50x128 / 8x25x256 / 4x13x512) -> 0.541 / 0.249 / 0.151.  The size is the
+  // same for every batch size (the order of the mean's additions depends on it, and results must not depend on the batch
+  // composition); MSOCR_SE_NT=256 selects the small workgroups.
+  static const int nt_env = getenv("MSOCR_SE_NT") ? atoi(getenv("MSOCR_SE_NT")) : 0;
+  const int NT = nt_env == 256 ? 256 : 1024;
+  const size_t lds = (size_t)((NT / (C / 4)) * C + 2 * C + C / 16) * sizeof(float);
+  if (dtype == MSOCR_F32) {
+    if (NT == 1024)
+      MSOCR_LAUNCH((se_residual_kernel<float, 1024>), dim3(N), dim3(1024), lds, s, (const float*)x, (const float*)identity, HW, C, w1, w2, gate_ws, (float*)out);
+    else
+      MSOCR_LAUNCH((se_residual_kernel<float, 256>), dim3(N), dim3(256), lds, s, (const float*)x, (const float*)identity, HW, C, w1, w2, gate_ws, (float*)out);
+  } else if (dtype == MSOCR_BF16) {
+    MSOCR_LAUNCH((se_residual_kernel<uint16_t, 256>), dim3(N), dim3(256), (size_t)((1024 / C) * C + 2 * C + C / 16) * sizeof(float), s,
+                 (const uint16_t*)x, (const uint16_t*)identity, HW, C, w1, w2, gate_ws, (uint16_t*)out);
+  } else {
     return MSOCR_E_ARG;
+  }
   return LAUNCH_OK();
 }
 
