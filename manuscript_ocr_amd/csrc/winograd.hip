@@ -865,6 +865,7 @@ static int wino42_fused_launch(const msocr_conv_desc* d, const void* u_weight, b
   static const bool v2 = !(getenv("MSOCR_WINO_FUSED_V2") && getenv("MSOCR_WINO_FUSED_V2")[0] == '0');
   if (split && v2 && d->Cout % 64 == 0) {
     const long nblk2 = ((g.Mt + 63) / 64) * (long)(d->Cout / 64);
+    if (nblk2 <= 0 || nblk2 > 0x7fffffffL) return MSOCR_E_ARG;
     const dim3 grid2((unsigned)nblk2);
     const unsigned short* up = (const unsigned short*)u_weight;
     if (d->flags & MSOCR_CONV_POOL2)

@@ -624,3 +624,27 @@ def test_built_library_has_no_cross_dword_packed_f32_instruction(tmp_path):
                     bad.append(line.strip())
     assert not bad, f"{len(bad)} cross-dword packed-f32 instructions, e.g. {bad[:3]}"
     assert packed > 0  # conv_split / conv_igemm keep their same-dword packed forms: the scan really saw device code
+
+
+def test_new_recurrent_entry_points_reject_bad_arguments_before_any_launch():
+    """msocr_bilstm_recurrent_split / msocr_attn_beam_hoisted validate their arguments first (no GPU is touched for these calls):
+    hidden sizes other than 256, null or misaligned packed planes, an xproj too large for 32-bit offsets, a split-weight struct with a
+    missing plane."""
+    import ctypes
+    from manuscript_ocr_amd import _native as nat
+    L = nat.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    assert L.msocr_bilstm_recurrent_split(p, p16, 4, 13, 128, p, None) != 0          # hidden size
+    assert L.msocr_bilstm_recurrent_split(p, None, 4, 13, 256, p, None) != 0         # no planes
+    assert L.msocr_bilstm_recurrent_split(p, p16 + 2, 4, 13, 256, p, None) != 0      # misaligned planes
+    assert L.msocr_bilstm_recurrent_split(p, p16, 1 << 20, 4, 256, p, None) != 0     # 2^20 x 4 x 2 x 1024 elements >= 2^32
+    aw = nat.AttnWeights()
+    for name, _ in aw._fields_:
+        setattr(aw, name, p)
+    sw = nat.AttnSplitWeights()
+    sw.h2h_p, sw.whh_p, sw.gen_p = p16, None, p16
+    args = (4, 13, 256, 194, 25, 8, None, 1.0, 1, 2, -1, p, p16, None, None, None, None)
+    assert L.msocr_attn_beam_hoisted(p, p, p16, ctypes.byref(aw), ctypes.byref(sw), *args) != 0   # a plane is missing
+    assert L.msocr_attn_beam_hoisted(p, p, None, ctypes.byref(aw), None, *args) != 0              # no hoisted product
