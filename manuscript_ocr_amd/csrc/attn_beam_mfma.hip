@@ -125,11 +125,12 @@ __device__ __forceinline__ void wave_argmax63(float& v, int& i) {
 
 // One-register f32 add / fused multiply-add that the compiler cannot pair into v_pk_add_f32 / v_pk_fma_f32.  The VALU work between
 // the softmax barrier and the gate MFMAs (token-row initialisation, the hoisted context sum) runs while faster waves of the same SIMD
-// are already inside their v_mfma_f32_32x32x16_bf16 loop.  Measured on MI355X (tools/attn_var.sh, 4 x 15360 state rows per form):
+// are already inside their v_mfma_f32_32x32x16_bf16 loop.  Measured on MI355X (tools/attn_packed_probe.sh, profiles/r03_attn_packed_probe.txt: 6 x 15360 state rows per form):
 // with the packed form of that sum — v_pk_fma_f32 ... op_sel:[0,1,0], the low result taking the high dword of a source pair — about
 // 0.5 % of the rows of the LAST crop processed came out with the low result of lanes 48..63 wrong (gate pre-activation off by 0.1 .. 1),
-// always there and only there, moving with the processing order of the crops; with one-register FMAs: 0 of 61440.  The same source
-// compiled for the exact-f32 kernel (16-pass f32 MFMAs beside it) never showed it.  tests/test_gpu_trba.py keeps a split-against-
+// always there and only there, moving with the processing order of the crops (488 of 92160 rows); with a workgroup barrier between the
+// sum and the MFMA loop: 0; with one-register FMAs: 0.  The same source compiled for the exact-f32 kernel (16-pass f32 MFMAs beside it)
+// never showed it.  This file is also compiled without packed-f32 instructions (Makefile), like every kernel that runs beside bf16 MFMAs.  tests/test_gpu_trba.py keeps a split-against-
 // exact comparison of every beam's logits as the guard.
 __device__ __forceinline__ float add_np(float a, float b) {
   float r;
