@@ -64,6 +64,22 @@ struct Mma<__bf16> {
   }
 };
 
+// two f32 -> (packed bf16 pair of the leading terms, the two residuals): one step of the exact three-term split of conv_split.hip
+__device__ __forceinline__ uint32_t split_step(float& x, float& y) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x, y};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+  const uint32_t pk = __builtin_bit_cast(uint32_t, h);
+  x -= __uint_as_float(pk << 16);          // exact: the leading term shares x's exponent
+  y -= __uint_as_float(pk & 0xffff0000u);
+  return pk;
+}
+
+// conv_split_pp.hip: the producer / consumer form of the split-operand kernel (Cout % 128 == 0); same ConvParams as conv_split_kernel
+__attribute__((visibility("hidden"))) bool msocr_internal_split_pp_takes(const ConvParams& p);
+__attribute__((visibility("hidden"))) int msocr_internal_split_pp_launch(ConvParams& p, hipStream_t s, bool general);
+
 // BKB = bytes per tile row (64 or 128).  swizzle: 16-B chunk index ^= (row / rows_per_256B) % chunks_per_row
 template <int BKB>
 __device__ __forceinline__ int swz(int row) {

@@ -27,18 +27,6 @@
 
 namespace {
 
-// two f32 -> (packed bf16 pair of the leading terms, the two residuals)
-__device__ __forceinline__ uint32_t split_step(float& x, float& y) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {x, y};
-  const bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
-  const uint32_t pk = __builtin_bit_cast(uint32_t, h);
-  x -= __uint_as_float(pk << 16);          // exact: the leading term shares x's exponent
-  y -= __uint_as_float(pk & 0xffff0000u);
-  return pk;
-}
-
 // 16 zero bytes: padded (out-of-image) taps of the general loader read from here
 __device__ __attribute__((aligned(16))) uint32_t msocr_split_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -292,11 +280,40 @@ int launch_split(ConvParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 
-int launch_split_any(ConvParams& p, hipStream_t s, bool general) {
-  // the lean loader addresses with 32-bit byte offsets from a uniform base: operands of 4 GB or more take the general loader (64-bit)
-  if (!general && ((p.M * p.sW + 32) * 4 >= (1L << 32) || ((long)p.Cout * p.Ktot + 32) * 2 >= (1L << 32))) general = true;
+// Kernel choice.  MSOCR_SPLIT_PP (default 1): shapes the producer / consumer kernel of conv_split_pp.hip has an instance for
+// (Cout % 128 == 0) go there; 0 keeps everything on conv_split_kernel (diagnostics, A/B timing).
+int launch_split_one(ConvParams& p, hipStream_t s, bool general) {
+  static int use_pp = -1;
+  if (use_pp < 0) {
+    const char* e = getenv("MSOCR_SPLIT_PP");
+    use_pp = e ? atoi(e) : 1;
+  }
+  if (use_pp && msocr_internal_split_pp_takes(p)) return msocr_internal_split_pp_launch(p, s, general);
   if (general) return p.Cout % 128 == 0 ? launch_split<128, 3, true>(p, s) : launch_split<64, 3, true>(p, s);
   return p.Cout % 128 == 0 ? launch_split<128, 3, false>(p, s) : launch_split<64, 3, false>(p, s);
+}
+
+// Both loaders address with a per-thread 32-bit byte offset from a wave-uniform base: the lean one unsigned (rows of ONE problem
+// must span less than 4 GB), the general one signed (an image range below 2 GB: msocr_conv2d_split splits the batch).  A lean
+// single-problem launch whose rows span more is cut into row ranges here (rows are independent; bases advance in 64 bits).
+int launch_split_any(ConvParams& p, hipStream_t s, bool general) {
+  if (((long)p.Cout * p.Ktot + 32) * 2 >= (1L << 32)) return MSOCR_E_ARG;
+  if (general) return launch_split_one(p, s, true);
+  const long row_b = p.sW * 4;
+  const long limit = (1L << 32) - 4096;
+  if ((p.M * p.sW + 32) * 4 < limit) return launch_split_one(p, s, false);
+  if (p.nbatch != 1 || row_b <= 0 || row_b * 256 >= limit) return MSOCR_E_ARG;
+  const long rows_per = (limit / row_b) & ~255L;   // a multiple of every M-tile
+  for (long m0 = 0; m0 < p.M; m0 += rows_per) {
+    ConvParams q = p;
+    q.M = p.M - m0 < rows_per ? p.M - m0 : rows_per;
+    q.in = p.in + m0 * row_b;
+    q.out = p.out + m0 * p.out_ld * 4;
+    if (p.has_res) q.res = p.res + m0 * p.res_ld * 4;
+    const int rc = launch_split_one(q, s, false);
+    if (rc != MSOCR_OK) return rc;
+  }
+  return MSOCR_OK;
 }
 
 }  // namespace
