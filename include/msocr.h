@@ -95,16 +95,24 @@ int msocr_winograd42_output_transform(const msocr_conv_desc* d, const void* work
  * the three dropped ones are <= 2^-25 of the product (below the rounding of the f32 accumulation itself).  The activation operand
  * is split in registers inside the kernel; the WEIGHT operand is split once at load time:
  *   msocr_split_bf16x3_host(w, n, planes)   HOST: w [n] f32 -> planes [3][n] bf16 (uint16), w == p0 + p1 + p2 exactly.
+ *   msocr_split_bf16x3_ktile_host(w, nb, rows, k, planes)   HOST: the same split of w [nb][rows][k] (k % 32 == 0) written
+ *     K-TILE-MAJOR, planes [3][nb][k/32][rows][32]: the 32-element pieces of all rows for one K-tile are contiguous (64 bytes per row),
+ *     so a workgroup's weight tile of one K-tile is ONE dense block — whole 128-byte lines, every byte used.  (Row-major planes
+ *     gave 64-byte pieces at a stride of 2 k bytes: half of every fetched line belonged to the NEXT K-tile and was fetched again —
+ *     TCP -> L2 read requests 2x the algorithmic count, profiles/r04_pp_ablations.txt.)  This is the layout the three GEMM entry
+ *     points below take ("weight_planes" / "u_planes"; k = KH * KW * Cin in the weight's own [KH][KW][Cin] order).
  * msocr_conv1x1_split: msocr_conv2d for KH = KW = 1 / stride 1 / no padding / MSOCR_F32 over a dense pixel sequence
- *   (in_sH == W * in_sW, in_sN == H * in_sH), Cin % 32 == 0, Cout % 64 == 0; weight_planes = [3][Cout][Cin] bf16 on the device.
+ *   (in_sH == W * in_sW, in_sN == H * in_sH), Cin % 32 == 0, Cout % 64 == 0; weight_planes = K-tile-major planes of [1][Cout][Cin] on the device.
  *   Same flags, epilogue and reference layers as msocr_conv2d (torchvision Bottleneck conv1 / conv3 / downsample, DecoderBlock
  *   conv1x1, SEBasicBlock downsample, the BiLSTM input projections and linears).
  * msocr_conv2d_split: msocr_conv2d for MSOCR_F32 with any kernel size / stride / padding (the strided 3x3 and 1x1 convolutions of
- *   the two ResNet trunks, which have no Winograd form), weight_planes = [3][Cout][KH][KW][Cin] bf16; Cin % 32 == 0, Cout % 64 == 0.
+ *   the two ResNet trunks, which have no Winograd form), weight_planes = K-tile-major planes of [1][Cout][KH*KW*Cin]; Cin % 32 == 0, Cout % 64 == 0.
  * msocr_winograd42_gemm_split / msocr_conv3x3_winograd42_split: stage 2 of / the whole msocr_conv3x3_winograd42 with
- *   u_planes = [3][24][Cout][Cin] bf16 = msocr_split_bf16x3_host of msocr_winograd42_weights_host's output (Cin % 32, Cout % 64).
+ *   u_planes = K-tile-major planes ([3][24][Cin/32][Cout][32] bf16) of msocr_winograd42_weights_host's [24][Cout][Cin] output
+ *   (Cin % 32, Cout % 64).
  * Results differ from the exact-f32 entry points by rounding only (tests/test_gpu_ops.py bounds both against an f64 reference). */
 int msocr_split_bf16x3_host(const float* w_host, int64_t n, uint16_t* planes_out_host);
+int msocr_split_bf16x3_ktile_host(const float* w_host, int64_t nbatch, int64_t rows, int64_t k, uint16_t* planes_out_host);
 int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
                         const void* residual, void* out, void* stream);
 int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,

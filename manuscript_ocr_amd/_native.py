@@ -59,6 +59,7 @@ _SIGS = {
     "msocr_winograd42_gemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_winograd42_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_split_bf16x3_host": (c_i32, [c_vp, c_i64, c_vp]),
+    "msocr_split_bf16x3_ktile_host": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp]),
     "msocr_conv1x1_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv2d_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_gemm_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),

@@ -36,6 +36,7 @@ struct ConvParams {
   int nbatch;           // independent problems of identical shape in one launch (Winograd: the 16 transform points)
   long bsA, bsW, bsO;   // element strides between consecutive problems (input, weight, output)
   long wplane;          // conv_split.hip: elements between the three bf16 planes of the split weight operand
+  long w_kt_b;          // conv_split.hip: bytes between consecutive K-tiles of a weight plane (K-tile-major planes: Cout * 64)
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
   for (int j = 0; j < B_IT; ++j) {
     int co = tile_n * BN + b_row0 + j * BRP;
     if (co >= p.Cout) co = p.Cout - 1;
-    b_off[j] = (uint32_t)(((long)co * p.Ktot + b_chunk * 8) * 2);
+    b_off[j] = (uint32_t)(co * 64 + b_chunk * 16);   // K-tile-major planes: [k/32][Cout][32]
   }
   const long wplane_b = p.wplane * 2;
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, WPE) void conv_split_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      const char* const gb = g_w + pl * wplane_b + (long)kt * (BK * 2);  // uniform
+      const char* const gb = g_w + pl * wplane_b + (long)kt * p.w_kt_b;  // uniform
 #pragma unroll
       for (int j = 0; j < B_IT; ++j)
         if (BN % BRP == 0 || b_row0 + j * BRP < BN) rb[pl][j] = *reinterpret_cast<const u32x4*>(gb + b_off[j]);
@@ -298,6 +298,7 @@ int launch_split_one(ConvParams& p, hipStream_t s, bool general) {
 // single-problem launch whose rows span more is cut into row ranges here (rows are independent; bases advance in 64 bits).
 int launch_split_any(ConvParams& p, hipStream_t s, bool general) {
   if (((long)p.Cout * p.Ktot + 32) * 2 >= (1L << 32)) return MSOCR_E_ARG;
+  p.w_kt_b = (long)p.Cout * 64;
   if (general) return launch_split_one(p, s, true);
   const long row_b = p.sW * 4;
   const long limit = (1L << 32) - 4096;
@@ -342,8 +343,27 @@ extern "C" int msocr_split_bf16x3_host(const float* w_host, int64_t n, uint16_t*
   return MSOCR_OK;
 }
 
-// 1x1 / stride 1 / no padding convolution (a GEMM over pixels) with the weight operand given as three bf16 planes
-// [3][Cout][Cin] (plane stride Cout * Cin).  Same descriptor, epilogue flags and error behaviour as msocr_conv2d.
+// HOST helper: the same split of w [nbatch][rows][k], planes written K-tile-major [3][nbatch][k/32][rows][32] (include/msocr.h).
+extern "C" int msocr_split_bf16x3_ktile_host(const float* w_host, int64_t nbatch, int64_t rows, int64_t k, uint16_t* planes_out_host) {
+  if (!w_host || !planes_out_host || nbatch <= 0 || rows <= 0 || k <= 0 || k % 32) return MSOCR_E_ARG;
+  const int64_t n = nbatch * rows * k;
+  uint16_t* tmp = (uint16_t*)malloc((size_t)n * 3 * sizeof(uint16_t));
+  if (!tmp) return MSOCR_E_ARG;
+  const int rc = msocr_split_bf16x3_host(w_host, n, tmp);
+  if (rc == MSOCR_OK) {
+    const int64_t kt = k / 32;
+    for (int pl = 0; pl < 3; ++pl)
+      for (int64_t b = 0; b < nbatch; ++b)
+        for (int64_t r = 0; r < rows; ++r)
+          for (int64_t t = 0; t < kt; ++t)
+            memcpy(planes_out_host + pl * n + ((b * kt + t) * rows + r) * 32, tmp + pl * n + (b * rows + r) * k + t * 32, 64);
+  }
+  free(tmp);
+  return rc;
+}
+
+// 1x1 / stride 1 / no padding convolution (a GEMM over pixels) with the weight operand given as three bf16 planes,
+// K-tile-major [3][Cin/32][Cout][32] (plane stride Cout * Cin).  Same descriptor, epilogue flags and error behaviour as msocr_conv2d.
 extern "C" int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
                                    const void* residual, void* out, void* stream) {
   if (!d || !in || !weight_planes || !out) return MSOCR_E_ARG;
@@ -373,7 +393,7 @@ extern "C" int msocr_conv1x1_split(const msocr_conv_desc* d, const void* in, con
   return launch_split_any(p, (hipStream_t)stream, false);
 }
 
-// Any kernel size / stride / padding with the weight operand as three bf16 planes [3][Cout][KH][KW][Cin] (the strided 3x3 and 1x1
+// Any kernel size / stride / padding with the weight operand as three K-tile-major bf16 planes of [Cout][KH*KW*Cin] (the strided 3x3 and 1x1
 // convolutions of the ResNet trunks that have no Winograd form).  Same descriptor rules as msocr_conv2d for MSOCR_F32, plus
 // Cin % 32 == 0 and Cout % 64 == 0.
 extern "C" int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, const void* weight_planes, const float* bias,
@@ -423,7 +443,7 @@ extern "C" int msocr_conv2d_split(const msocr_conv_desc* d, const void* in, cons
 }
 
 // nbatch independent GEMMs of one shape in ONE launch, C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]: A f32 [nbatch][M][K],
-// B as three bf16 planes [3][nbatch][N][K], C f32 [nbatch][M][N].  The Winograd-domain GEMMs (winograd.hip).
+// B as three K-tile-major bf16 planes [3][nbatch][K/32][N][32], C f32 [nbatch][M][N].  The Winograd-domain GEMMs (winograd.hip).
 int msocr_internal_gemm_split_batched(const float* A, const uint16_t* Bplanes, float* C, long M, int N, int K, int nbatch, hipStream_t s) {
   if (!A || !Bplanes || !C || M <= 0 || N <= 0 || N % 64 || K <= 0 || K % 32 || nbatch <= 0) return MSOCR_E_ARG;
   if (((uintptr_t)A | (uintptr_t)Bplanes | (uintptr_t)C) & 15) return MSOCR_E_ARG;

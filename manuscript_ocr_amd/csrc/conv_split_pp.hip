@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
       for (int j = 0; j < B_IT; ++j) {
         int co = tile_n * BN + b_row0 + j * BRP;
         if (co >= p.Cout) co = p.Cout - 1;
-        b_off[j] = (uint32_t)(((long)co * p.Ktot + b_chunk * 8) * 2);
+        b_off[j] = (uint32_t)(co * 64 + b_chunk * 16);   // K-tile-major planes [k/32][Cout][32]: the tile's rows are one dense block
       }
     };
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
       constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
-        const char* const gb = gb_base + pl * wplane_b + (long)bkt * (BK * 2);   // uniform
+        const char* const gb = gb_base + pl * wplane_b + (long)bkt * p.w_kt_b;   // uniform
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) rb[BUF][pl][j] = *reinterpret_cast<const u32x4*>(gb + b_off[j]);
       }

@@ -8,7 +8,7 @@
 __attribute__((visibility("hidden"))) int msocr_internal_gemm_f32_batched(const float* A, const float* B, float* C, long M, int N,
                                                                           int K, int nbatch, hipStream_t s);
 
-// conv_split.hip: the same with B given as three bf16 planes [3][nbatch][N][K] (B == p0 + p1 + p2 exactly), A split in
+// conv_split.hip: the same with B given as three K-tile-major bf16 planes [3][nbatch][K/32][N][32] (B == p0 + p1 + p2 exactly), A split in
 // registers: six bf16 MFMA products per f32 product, f32 accumulate (K % 32 == 0, N % 64 == 0).
 __attribute__((visibility("hidden"))) int msocr_internal_gemm_split_batched(const float* A, const uint16_t* Bplanes, float* C, long M,
                                                                             int N, int K, int nbatch, hipStream_t s);

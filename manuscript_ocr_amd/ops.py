@@ -122,6 +122,23 @@ def split_planes(t):
     return planes.view(torch.bfloat16).to(t.device)
 
 
+def split_planes_ktile(t, nbatch, rows):
+    """f32 tensor viewed as [nbatch][rows][k] -> bf16 planes [3, nbatch, k/32, rows, 32] on t's device: the K-tile-major layout the
+    split-operand GEMM kernels read (msocr_split_bf16x3_ktile_host; include/msocr.h says why)."""
+    th = t.detach().float().cpu().contiguous()
+    k = th.numel() // (nbatch * rows)
+    assert k % 32 == 0 and nbatch * rows * k == th.numel()
+    planes = torch.empty((3, nbatch, k // 32, rows, 32), dtype=torch.int16)
+    nat.check(nat.lib().msocr_split_bf16x3_ktile_host(th.data_ptr(), nbatch, rows, k, planes.data_ptr()), "split_bf16x3_ktile_host")
+    return planes.view(torch.bfloat16).to(t.device)
+
+
+def unsplit_planes_ktile(planes):
+    """Inverse of split_planes_ktile for tests: planes [3, nb, k/32, rows, 32] -> f32 [nb, rows, k] = p0 + p1 + p2."""
+    nb, kt, rows = planes.shape[1:4]
+    return planes.float().sum(0).permute(0, 2, 1, 3).reshape(nb, rows, kt * 32)
+
+
 # Below this reduction length (KH * KW * Cin) a convolution stays on the exact-f32 kernel: the split kernel's K-tiles of 32 with two
 # barriers each lose to the exact lean kernel's K-tiles of 16 at K = 64 (55 against 64 TFLOP/s, profiles/r03_conv_layers_split_all.txt;
 # these layers sit at 0.78 of their HBM roofline anyway).  Whole pipeline, same box, after the split kernel lost its spill:
@@ -143,7 +160,7 @@ def attach_split(w, split=None):
         return w
     Cout, KH, KW, Cin = w.shape
     if (SPLIT_BF16X3 if split is None else split) and KH == 1 and KW == 1 and _split_eligible(w):
-        w._msocr_split = split_planes(w)
+        w._msocr_split = split_planes_ktile(w, 1, Cout)
     return w
 
 
@@ -175,7 +192,7 @@ def attach_winograd(w, split=None):
     nat.check(nat.lib().msocr_winograd42_weights_host(wh.data_ptr(), Cout, Cin, u42.data_ptr()), "winograd42_weights_host")
     w._msocr_wino42 = u42.to(w.device)
     if (SPLIT_BF16X3 if split is None else split) and Cin % 32 == 0 and Cout % 64 == 0:
-        w._msocr_wino42_split = split_planes(u42).to(w.device)  # [3][24][Cout][Cin] bf16
+        w._msocr_wino42_split = split_planes_ktile(u42, 24, Cout).to(w.device)  # [3][24][Cin/32][Cout][32] bf16
     return w
 
 
@@ -321,7 +338,7 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
         wp = getattr(w, "_msocr_split", None)
         if (wp is None and SPLIT_BF16X3 and not getattr(w, "_msocr_nosplit", False) and _split_eligible(w)
                 and not torch.cuda.is_current_stream_capturing()):
-            wp = w._msocr_split = split_planes(w)  # first use of this weight outside the Winograd path: split once, keep
+            wp = w._msocr_split = split_planes_ktile(w, 1, Cout)  # first use of this weight outside the Winograd path: split once, keep
         split = wp is not None and SPLIT_BF16X3 and KH * KW * Cin >= SPLIT_MIN_K and all(v % 4 == 0 for v in x.stride()[:3])
         lean = (split and (KH, KW, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and (Ho, Wo) == (H, W)
                 and (H == 1 or x.stride(1) == W * x.stride(2)) and (N == 1 or x.stride(0) == H * W * x.stride(2)))

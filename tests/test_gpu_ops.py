@@ -163,8 +163,8 @@ def test_conv1x1_split_vs_exact_and_f64(ops, case, monkeypatch):
     rd = res.cuda() if use_res else None
     w_e = ops.attach_split(w.cuda(), False)   # exact-f32 only
     w_s = ops.attach_split(w.cuda(), True)
-    assert w_s._msocr_split.shape == (3, Cout, 1, 1, Cin) and w_s._msocr_split.dtype == torch.bfloat16
-    assert torch.equal(w_s._msocr_split.float().sum(0).cpu(), w)  # the planes add up to the weight exactly
+    assert w_s._msocr_split.shape == (3, 1, Cin // 32, Cout, 32) and w_s._msocr_split.dtype == torch.bfloat16  # K-tile-major
+    assert torch.equal(ops.unsplit_planes_ktile(w_s._msocr_split).cpu().view(Cout, 1, 1, Cin), w)  # the planes add up to the weight exactly
     out_e = ops.conv2d(xd, w_e, b.cuda(), relu=relu, residual=rd)
     big = torch.full((N, H, W, Cout + 32), 7.0, device="cuda")
     ops.PROFILE = []
@@ -201,7 +201,7 @@ def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
     xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
     w_e = ops.attach_winograd(_w_khwc(w, torch.float32), False)
     w_s = ops.attach_winograd(_w_khwc(w, torch.float32), True)
-    assert not hasattr(w_e, "_msocr_wino42_split") and w_s._msocr_wino42_split.shape == (3, 24, Cout, Cin)
+    assert not hasattr(w_e, "_msocr_wino42_split") and w_s._msocr_wino42_split.shape == (3, 24, Cin // 32, Cout, 32)
     out_e = ops.conv2d(xd, w_e, b.cuda(), (1, 1), (1, 1), relu, rd)
     ops.PROFILE = []
     out_s = ops.conv2d(xd, w_s, b.cuda(), (1, 1), (1, 1), relu, rd)
