@@ -123,28 +123,22 @@ __device__ __forceinline__ void wave_argmax63(float& v, int& i) {
   argmax_step<DPP_BCAST31, 0xC>(v, i);
 }
 
-// One-register f32 add / fused multiply-add that the compiler cannot pair into v_pk_add_f32 / v_pk_fma_f32.  The VALU work between
-// the softmax barrier and the gate MFMAs (token-row initialisation, the hoisted context sum) runs while faster waves of the same SIMD
-// are already inside their v_mfma_f32_32x32x16_bf16 loop.  Measured on MI355X (tools/attn_packed_probe.sh, profiles/r03_attn_packed_probe.txt: 6 x 15360 state rows per form):
-// with the packed form of that sum — v_pk_fma_f32 ... op_sel:[0,1,0], the low result taking the high dword of a source pair — about
-// 0.5 % of the rows of the LAST crop processed came out with the low result of lanes 48..63 wrong (gate pre-activation off by 0.1 .. 1),
-// always there and only there, moving with the processing order of the crops (488 of 92160 rows); with a workgroup barrier between the
-// sum and the MFMA loop: 0; with one-register FMAs: 0.  The same source compiled for the exact-f32 kernel (16-pass f32 MFMAs beside it)
-// never showed it.  This file is also compiled without packed-f32 instructions (Makefile), like every kernel that runs beside bf16 MFMAs.  tests/test_gpu_trba.py keeps a split-against-
-// exact comparison of every beam's logits as the guard.
-__device__ __forceinline__ float add_np(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float fmac_np(float a, float b, float c) {
-#ifdef MSOCR_ATTN_PACKED_SUM  // dev builds (tools/attn_packed_probe.sh): the form the compiler pairs into v_pk_fma_f32
-  return fmaf(a, b, c);
-#else
-  asm("v_fmac_f32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-#endif
-}
+// Packed-f32 VALU beside bf16 MFMAs.  The VALU work between the softmax barrier and the gate MFMAs (token-row initialisation, the
+// hoisted context sum) runs while the other wave of the SIMD is inside its v_mfma_f32_32x32x16_bf16 loop.  Round 3 found that with
+// the packed form the compiler chose for that sum — v_pk_fma_f32 ... op_sel:[0,1,0], the LOW result taking the HIGH dword of a
+// source pair — about 0.5 % of the state rows came out with the low result of lanes 48..63 wrong (tools/attn_packed_probe.sh,
+// profiles/r03_attn_packed_probe.txt).  Round 4 settled the cause: the disassembly of that build has hundreds of cycles (a branch,
+// twelve buffer loads, an s_waitcnt vmcnt) between the last v_pk_fma_f32 that writes an accumulator and the first MFMA that reads it
+// as SrcC, so it is no missing VALU -> MFMA wait state; and the 90-line stand-alone tools/microbench/pk_fma_beside_mfma.hip
+// reproduces it with nothing else in the kernel — 22 880 wrong low results, all in lanes 48..63, out of 2.6e9 with the partner waves
+// running v_mfma_f32_32x32x16_bf16; 0 with idle partners; 0 for the same instruction without op_sel (profiles/r04_pk_fma_probe.txt).
+// It is a property of the instruction beside MFMAs, not of this kernel's code.  The remedy is at build level: this file, like every
+// translation unit whose kernels run beside bf16 MFMAs, is compiled without packed-f32 instructions (csrc/Makefile, NOPK_OBJS), the
+// sums below are plain C (the compiler's hazard recognizer sees them — round 3's inline asm hid them from it), and
+// tests/test_host_cpu.py::test_no_packed_f32_valu_beside_mfma disassembles the built objects.  tests/test_gpu_trba.py keeps the
+// split-against-exact comparison of every beam's logits as the run-time guard.
+__device__ __forceinline__ float add_np(float a, float b) { return a + b; }
+__device__ __forceinline__ float fmac_np(float a, float b, float c) { return fmaf(a, b, c); }
 
 
 // Weight streams use buffer loads: ONE per-lane byte offset in a VGPR (loop-invariant) + a scalar byte offset per load, so

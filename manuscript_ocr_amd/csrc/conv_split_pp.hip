@@ -1,25 +1,32 @@
 // conv_split_pp.hip — the split-operand ("bf16x3") f32 GEMM / convolution of conv_split.hip as a PRODUCER / CONSUMER workgroup.
 //
-// Same arithmetic as conv_split_kernel (an f32 value is the exact sum of three bf16 values; six of the nine cross products on
-// v_mfma_f32_32x32x16_bf16, smallest terms first, f32 accumulate, the same order of additions per output element), different
-// machine mapping (round 4).  conv_split_kernel's four waves each load, split, stage, multiply and meet at two barriers per
-// K-tile; its matrix pipes idle while a workgroup splits and stages (PMC: 0.48 busy).  Here a 512-thread workgroup puts TWO
-// waves on every SIMD with fixed roles (MI355X_MICROARCH.md, "Two waves per SIMD"):
-//   waves 0-3  CONSUMERS: nothing but ds_read_b128 + MFMA.  2 x 2 waves, wave tile (32 TM) x (32 TN) = 64 x 128 or 128 x 64, the
-//              128 accumulator registers of a wave live across the whole K loop.  Fragments are double-buffered in registers: the
-//              reads of the next unit (one 32-wide block of the streamed operand x all blocks of the held operand, 12 MFMAs) are
-//              in flight under the MFMAs of the current one, across the barrier too.
-//   waves 4-7  PRODUCERS: global -> registers (two K-tiles in flight) -> split in registers (v_cvt_pk_bf16_f32 + exact
-//              residuals) -> LDS.  Their VALU and memory instructions issue in the gaps of the partner wave's MFMAs.
-// Two LDS stages of six [rows][64 B] planes (3 x (BM + BN) x 64 B = 72 KB each), ONE barrier per K-tile of 96 MFMAs per consumer
-// wave (conv_split_kernel: two per 48).  The workgroup is persistent: a static, XCD-contiguous list of output tiles per
-// workgroup; the producers run ahead across tile boundaries, so the first K-tiles of the next tile load while the consumers
-// store the finished one (straight from the accumulators: 2 x 128-byte segments per store instruction, no LDS pass).
+// Same arithmetic idea as conv_split_kernel (an f32 value is the exact sum of three bf16 values; six of the nine cross products on
+// the bf16 matrix pipes, smallest terms first, f32 accumulate), different machine mapping (round 4):
 //
-// Tile 128 x 256 (Cout % 256 == 0) halves the activation re-splits and re-reads per output column block against the 128 x 128 of
-// conv_split_kernel; 256 x 128 serves Cout % 128 == 0.  Everything else stays on conv_split_kernel.
+//   * 512-thread workgroup, TWO waves on every SIMD with fixed roles (MI355X_MICROARCH.md, "Two waves per SIMD"):
+//       waves 0-3  CONSUMERS: ds_read_b128 + MFMA only.  2 x 2 waves, wave tile 64 x 128 (or 128 x 64) = 32 blocks of 16 x 16, the
+//                  128 accumulator registers live across the whole K loop.
+//       waves 4-7  PRODUCERS: global -> registers (two K-tiles in flight) -> exact split in registers -> LDS.  No packed-f32 VALU
+//                  (the Makefile compiles this file without them): 16 v_pk_add_f32 per K-tile beside the partner's MFMAs cost 0.13
+//                  of the matrix pipes' busy fraction (profiles/r04_pp_ablations.txt).
+//     Two LDS stages of six [rows][64 B] planes (72 KB each), ONE barrier per K-tile (conv_split_kernel: two, and half the MFMAs
+//     between them).  Persistent: a static, XCD-contiguous list of output tiles per workgroup; the producers run ahead across tile
+//     boundaries.
+//   * v_mfma_f32_16x16x32_bf16 instead of 32x32x16: on random data the chip holds a higher clock on it — 337 against 299 TFLOP/s
+//     f32-equivalent for this very loop (tools/microbench/mfma_energy.hip, profiles/r04_mfma_energy_microbench.txt); the kernel is
+//     power-limited (0.83 pipe-busy at 1.42 GHz at K = 4096), so that is wall time.
+//   * CHUNKED ACCUMULATION: the six products of one 32-deep K-tile are chained from C = 0 into a 4-register partial sum (roundings
+//     at the size of a 32-term partial dot product) and that partial is added to the accumulator ONCE (v_add_f32 in the MFMAs'
+//     shadow).  conv_split_kernel rounds at the accumulator's magnitude 12 times per 32 k, this kernel once: measured against an
+//     f64 evaluation of the whole network the device's error drops accordingly (tests/test_gpu_f64.py).
+//   * The epilogue overlaps the next tile: block (i, j) of the finished tile is stored (bias, ReLU; 16-byte stores, each lane 4
+//     consecutive output channels — the MFMA runs with the weight fragment as its A operand, so a lane holds D[n .. n+3][m]) just
+//     before the next tile's first K-tile overwrites it; the stores drain under that tile's K loop.  Bias values reach the
+//     consumers through LDS (written by the producers with every K-tile), so the consumers issue no vector-memory loads at all.
 //
-// Reference layers: recognizers/_trba/model/seresnet31.py:37-67 ; detectors/_east/east.py:13-30 ; torchvision Bottleneck.
+// Tile 128 x 256 (Cout % 256 == 0) or 256 x 128 (Cout % 128 == 0); launches with a residual operand and all other shapes stay on
+// conv_split_kernel.  Reference layers: recognizers/_trba/model/seresnet31.py:37-67 ; detectors/_east/east.py:13-30 ; torchvision
+// Bottleneck.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -52,25 +59,29 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// One dword per lane to sbase (uniform, SGPR pair) + voff (per lane, 32 bits) + OFF: the saddr form costs no 64-bit VGPR address per
-// store (written as C the compiler builds 64-bit per-row addresses in VGPRs and spills them beside the 200 live registers).
+// 16 bytes per lane to sbase (uniform, SGPR pair) + voff (per lane, 32 bits) + OFF: the saddr form costs no 64-bit VGPR address
+// per store.  Inline asm: the compiler's vmcnt bookkeeping does not see these stores — the consumers never wait on vector memory.
 template <int OFF>
-__device__ __forceinline__ void store_f32_saddr(const char* sbase, uint32_t voff, float v) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
+__device__ __forceinline__ void store_f32x4_saddr(const char* sbase, uint32_t voff, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 
-// TM x TN = 32x32 blocks per consumer wave (2 x 4 or 4 x 2).  GEN as in conv_split_kernel: false = a K-tile is a pointer
+// LDS rows are 64 bytes (one K-tile of 32 bf16); a 16x16x32 fragment read takes 16-byte chunk lane / 16 of row lane % 16.  This
+// XOR of the chunk index by row makes every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) hit 16
+// distinct 16-byte slots (tools/microbench/mfma_energy.hip uses the same map; checked with SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int swz16(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+// TM x TN = 32-row x 32-column units per consumer wave (2 x 4 or 4 x 2).  GEN as in conv_split_kernel: false = a K-tile is a pointer
 // increment (1x1 / stride 1 / no padding over a dense pixel sequence, batched GEMMs); true = taps / stride / padding.
-// DBG (timing ablations, wrong results by construction, MSOCR_PP_DBG): 1 = no global loads after the prologue, 2 = producers only
-// meet the barriers, 4 = consumers issue no MFMA, 8 = consumers read no fragments after the first, 16 / 32 = no B / no A loads after the prologue, 64 = no output stores, 128 = no split arithmetic (raw bits stored).
-template <int TM, int TN, bool GEN, int DBG = 0, int DA_ = 2>
+template <int TM, int TN, bool GEN>
 __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int prio) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, ROWB = 64;
   constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
   constexpr int STAGE_B = 3 * (A_PLANE + B_PLANE);
-  constexpr bool STREAM_B = TN >= TM;          // the operand with more blocks streams through, the other is held per k16 step
-  constexpr int TH = STREAM_B ? TM : TN, TS = STREAM_B ? TN : TM;
-  constexpr int UNITS = 2 * TS;                // per K-tile: 2 k16 steps x TS streamed blocks, 6 * TH MFMAs each
+  constexpr int BIAS_OFF = 2 * STAGE_B;        // 4 slots of BN floats behind the two stages
+  constexpr int RM = 2 * TM, RN = 2 * TN;      // 16 x 16 blocks per consumer wave
+  constexpr bool STREAM_B = TN >= TM;          // the operand with more blocks streams through, the other is held for the K-tile
+  constexpr int RH = STREAM_B ? RM : RN, RS = STREAM_B ? RN : RM;   // held / streamed blocks: 4 / 8
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -90,36 +101,37 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
   const int G = my_tiles * p.ktiles;           // K-tiles this workgroup stages and multiplies
   if (G == 0) return;                          // uniform over the workgroup, before any barrier
 
+  auto tile_coords = [&](int n, int& batch, int& tile_m, int& tile_n) __attribute__((always_inline)) {
+    int t = x_start + slot + n * per_x;
+    batch = t / nblk1;
+    t -= batch * nblk1;
+    tile_n = t % p.tilesN;
+    tile_m = t / p.tilesN;
+  };
+
   if (wave >= 4) {
     // =========================================== PRODUCERS ===========================================
-    // Prefetch distances: the activation operand streams from HBM — its loads are issued DA = 4 K-tiles ahead of the store that
-    // consumes them; the weight planes come from L2 — DB = 2 ahead.  (With both at 2 the producers arrived late at every barrier:
-    // matrix pipes 0.62 busy against 0.80 with the loads removed, profiles/r04_pp_ablations.txt.)  vmcnt retires in issue order, so
-    // inside an iteration B is issued before A: waiting for a B tile then never waits for the younger A tiles.
-    constexpr int DA = DA_, DB = 2;
-    constexpr int UNR = DA % 2 ? 2 * DA : DA;   // lcm(DA, DB): the register buffers cycle with the iteration number
+    // Loads are issued two K-tiles ahead of the store that consumes them, B before A inside an iteration.  (Deeper prefetch was
+    // measured and changes nothing: the loads were never the stall, profiles/r04_pp_ablations.txt.)
+    constexpr int D = 2;
     const int ltid = tid & 255;
     constexpr int ACH = 8, ARP = 32, A_IT = BM / ARP;   // A: 8 x 16-B chunks per 128-B f32 row, 32 rows per pass
     constexpr int BCH = 4, BRP = 64, B_IT = BN / BRP;   // B: 4 x 16-B chunks per 64-B bf16 row, 64 rows per pass
     const int a_chunk = ltid % ACH, a_row0 = ltid / ACH;
     const int b_chunk = ltid % BCH, b_row0 = ltid / BCH;
     const long wplane_b = p.wplane * 2;
+    const int bias_i = ltid < BN ? ltid : BN - 1;       // this thread's column of the tile's bias slice
 
-    // two independent positions in the workgroup's (tile, K-tile) sequence: the next A tile and the next B tile to fetch
+    // two positions in the workgroup's (tile, K-tile) sequence: the next A tile and the next B tile (+ bias) to fetch
     uint32_t a_off[A_IT], b_off[B_IT];
     int a_hi0[GEN ? A_IT : 1], a_wi0[GEN ? A_IT : 1];
     const char* ga_base = nullptr;
     const char* gb_base = nullptr;
+    const float* gbias = nullptr;
     int an = 0, akt = 0, bn = 0, bkt = 0;
+    int sn = 0, skt = 0;                       // tile / K-tile of the next store
     int t_kh = 0, t_kw = 0, t_c0 = 0;          // GEN: tap and channel offset of the next A tile
 
-    auto tile_coords = [&](int n, int& batch, int& tile_m, int& tile_n) __attribute__((always_inline)) {
-      int t = x_start + slot + n * per_x;
-      batch = t / nblk1;
-      t -= batch * nblk1;
-      tile_n = t % p.tilesN;
-      tile_m = t / p.tilesN;
-    };
     auto set_tile_a = [&](int n) __attribute__((always_inline)) {
       int batch, tile_m, tile_n;
       tile_coords(n, batch, tile_m, tile_n);
@@ -146,6 +158,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
       int batch, tile_m, tile_n;
       tile_coords(n, batch, tile_m, tile_n);
       gb_base = p.w + (long)batch * p.bsW * 2;
+      // no bias: every lane reads the same zero word (the load stays unconditional, see below)
+      gbias = p.bias ? p.bias + tile_n * BN + bias_i : reinterpret_cast<const float*>(msocr_pp_zero16);
 #pragma unroll
       for (int j = 0; j < B_IT; ++j) {
         int co = tile_n * BN + b_row0 + j * BRP;
@@ -157,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
     // Loads are issued UNCONDITIONALLY — past the last K-tile of the last tile the position wraps to that tile's first K-tile (valid
     // addresses, values never multiplied) — so that the number of loads in flight at every wait is a compile-time constant: with a
     // conditional load the compiler must assume the shorter queue and its s_waitcnt vmcnt(N) drains the prefetch.
-    u32x4 ra[DA][A_IT], rb[DB][3][B_IT];
+    u32x4 ra[D][A_IT], rb[D][3][B_IT];
+    float rbias[D];
     auto load_a = [&](auto buf_c) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_c)::value;
       if constexpr (GEN) {
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
     };
     auto load_b = [&](auto buf_c) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_c)::value;
+      rbias[BUF] = *gbias;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         const char* const gb = gb_base + pl * wplane_b + (long)bkt * p.w_kt_b;   // uniform
@@ -198,27 +214,22 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
         if (bn + 1 < my_tiles) set_tile_b(++bn);
       }
     };
-    auto store = [&](auto abuf_c, auto bbuf_c, int stage) __attribute__((always_inline)) {
-      constexpr int AB = decltype(abuf_c)::value, BB = decltype(bbuf_c)::value;
+    auto store = [&](auto buf_c, int stage) __attribute__((always_inline)) {
+      constexpr int BUF = decltype(buf_c)::value;
       unsigned char* const sA = smem + stage * STAGE_B;   // [3][BM][ROWB]
       unsigned char* const sB = sA + 3 * A_PLANE;         // [3][BN][ROWB]
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int row = a_row0 + i * ARP;
-        float x0 = __uint_as_float(ra[AB][i][0]), x1 = __uint_as_float(ra[AB][i][1]);
-        float x2 = __uint_as_float(ra[AB][i][2]), x3 = __uint_as_float(ra[AB][i][3]);
+        float x0 = __uint_as_float(ra[BUF][i][0]), x1 = __uint_as_float(ra[BUF][i][1]);
+        float x2 = __uint_as_float(ra[BUF][i][2]), x3 = __uint_as_float(ra[BUF][i][3]);
         // this thread's 4 elements are bf16 positions 4 * a_chunk .. + 3 of the row: half of 16-B chunk a_chunk / 2
-        unsigned char* dst = sA + row * ROWB + (((a_chunk >> 1) ^ swz<ROWB>(row)) << 4) + ((a_chunk & 1) << 3);
+        unsigned char* dst = sA + row * ROWB + (((a_chunk >> 1) ^ swz16(row)) << 4) + ((a_chunk & 1) << 3);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           u32x2 v;
-          if constexpr (DBG & 128) {
-            v[0] = ra[AB][i][pl];
-            v[1] = ra[AB][i][pl + 1];
-          } else {
-            v[0] = split_step(x0, x1);
-            v[1] = split_step(x2, x3);
-          }
+          v[0] = split_step(x0, x1);
+          v[1] = split_step(x2, x3);
           *reinterpret_cast<u32x2*>(dst + pl * A_PLANE) = v;
         }
       }
@@ -227,134 +238,124 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
           const int row = b_row0 + j * BRP;
-          *reinterpret_cast<u32x4*>(sB + pl * B_PLANE + row * ROWB + ((b_chunk ^ swz<ROWB>(row)) << 4)) = rb[BB][pl][j];
+          *reinterpret_cast<u32x4*>(sB + pl * B_PLANE + row * ROWB + ((b_chunk ^ swz16(row)) << 4)) = rb[BUF][pl][j];
         }
+      // the bias slice of this K-tile's output tile, slot (tile number) % 4: rewritten with every K-tile of the tile (same values),
+      // read by the consumers one tile later, overwritten four tiles later
+      if (BN == 256 || ltid < BN) *reinterpret_cast<float*>(smem + BIAS_OFF + ((sn & 3) * BN + ltid) * 4) = rbias[BUF];
+      if (++skt == p.ktiles) { skt = 0; ++sn; }
     };
 
     set_tile_a(0);
     set_tile_b(0);
     load_b(ic<0>{});
-    static_for<0, DA - 1>([&](auto d) __attribute__((always_inline)) { load_a(d); });      // A tiles 0 .. DA-2
+    load_a(ic<0>{});
     load_b(ic<1>{});
-    load_a(ic<DA - 1>{});
-    store(ic<0>{}, ic<0>{}, 0);
+    load_a(ic<1>{});
+    store(ic<0>{}, 0);
     lds_barrier();                                         // #0: stage 0 is full
-    // iteration g (K-tile g is being multiplied from stage g % 2): fetch B tile g + DB and A tile g + DA into the registers K-tile g
-    // used, store K-tile g + 1 into the other stage (after the last K-tile: a stage nobody reads any more)
+    // iteration g (K-tile g is being multiplied from stage g % 2): fetch K-tile g + 2 into the registers K-tile g used, store
+    // K-tile g + 1 into the other stage (after the last K-tile: a stage nobody reads any more)
     for (int g = 0;;) {
-      bool done = false;
-      static_for<0, UNR>([&](auto r_c) __attribute__((always_inline)) {
-        constexpr int R = decltype(r_c)::value;
-        if (done) return;
-        if (!(DBG & 3)) {
-          if (!(DBG & 16)) load_b(ic<R % DB>{});
-          if (!(DBG & 32)) load_a(ic<R % DA>{});
-        }
-        if (!(DBG & 2)) store(ic<(R + 1) % DA>{}, ic<(R + 1) % DB>{}, (R + 1) & 1);
-        lds_barrier();                                     // #(g + 1)
-        if (++g >= G) done = true;
-      });
-      if (done) break;
+      load_b(ic<0>{});
+      load_a(ic<0>{});
+      store(ic<1>{}, 1);
+      lds_barrier();                                       // #(g + 1)
+      if (++g >= G) break;
+      load_b(ic<1>{});
+      load_a(ic<1>{});
+      store(ic<0>{}, 0);
+      lds_barrier();
+      if (++g >= G) break;
     }
     return;
   }
 
   // =========================================== CONSUMERS ===========================================
   if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, half = lane >> 5;
-  // fragment addresses inside a stage: row * 64 + ((chunk ^ swz(row)) << 4), chunk = 2 q + half; rows are r32 + multiples of 32,
+  const int r16 = lane & 15, kg = lane >> 4;
+  // fragment address inside a stage: row * 64 + ((chunk ^ swz16(row)) << 4), chunk = lane / 16; rows are r16 + multiples of 16,
   // so the swizzle depends on the lane only
-  const int sw = swz<ROWB>(r32);
-  uint32_t offA[2], offB[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c16 = ((2 * q + half) ^ sw) << 4;
-    offA[q] = (uint32_t)((wm * 32 * TM + r32) * ROWB + c16);
-    offB[q] = (uint32_t)(3 * A_PLANE + (wn * 32 * TN + r32) * ROWB + c16);
-  }
+  const uint32_t c16 = (uint32_t)((kg ^ swz16(r16)) << 4);
+  const uint32_t offA = (uint32_t)((wm * 32 * TM + r16) * ROWB) + c16;
+  const uint32_t offB = (uint32_t)(3 * A_PLANE + (wn * 32 * TN + r16) * ROWB) + c16;
+  const uint32_t offH = STREAM_B ? offA : offB, offS = STREAM_B ? offB : offA;
+  constexpr int PLANE_H = STREAM_B ? A_PLANE : B_PLANE, PLANE_S = STREAM_B ? B_PLANE : A_PLANE;
 
-  bf16x8 fh[2][3][TH], fs[2][3];
-  // reads of unit u (k16 step q = u / TS, streamed block s = u % TS) from the stage at byte offset so
-  auto issue_reads = [&](auto u_c, uint32_t so) __attribute__((always_inline)) {
-    constexpr int U = decltype(u_c)::value;
-    constexpr int q = U / TS, s = U % TS;
-    const unsigned char* const base = smem + so;
-    if constexpr (s == 0) {
+  bf16x8 fh[3][RH], fs[2][3];
+  auto read_held = [&](auto h_c, uint32_t so) __attribute__((always_inline)) {
+    constexpr int H = decltype(h_c)::value;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) fh[pl][H] = *reinterpret_cast<const bf16x8*>(smem + so + offH + pl * PLANE_H + H * 16 * ROWB);
+  };
+  auto read_stream = [&](auto s_c, uint32_t so) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value;
 #pragma unroll
-        for (int h = 0; h < TH; ++h)
-          fh[q][pl][h] = *reinterpret_cast<const bf16x8*>(base + (STREAM_B ? offA[q] + pl * A_PLANE : offB[q] + pl * B_PLANE) + h * 32 * ROWB);
-    }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      fs[U & 1][pl] = *reinterpret_cast<const bf16x8*>(base + (STREAM_B ? offB[q] + pl * B_PLANE : offA[q] + pl * A_PLANE) + s * 32 * ROWB);
+    for (int pl = 0; pl < 3; ++pl) fs[S & 1][pl] = *reinterpret_cast<const bf16x8*>(smem + so + offS + pl * PLANE_S + S * 16 * ROWB);
   };
 
-  f32x16 acc[TM][TN];
-  // FIRST: the unit's blocks start a new output tile — their first MFMA takes C = 0 instead of the accumulator
-  auto mfma_unit = [&](auto u_c, auto first_c) __attribute__((always_inline)) {
-    constexpr int U = decltype(u_c)::value;
-    constexpr bool FIRST = decltype(first_c)::value != 0;
-    constexpr int q = U / TS, s = U % TS;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // smallest terms first (conv_split_kernel's order per accumulator); the held blocks alternate
+  f32x4 acc[RM][RN];
+  // One 16 x 16 block, one K-tile: chain() runs the six products from C = 0, smallest terms first, into a 4-register partial sum;
+  // commit() adds that partial to the accumulator — ONE rounding at the accumulator's magnitude per 32 k (FIRST: the block starts a
+  // new output tile, the partial IS the accumulator).  The weight fragment is the MFMA's A operand: the lane holds D[n .. n+3][m],
+  // four consecutive output channels of pixel m.  Commits trail the chains by ONE UNIT (two sets of partial sums), so the
+  // additions issue in the shadow of the next unit's MFMAs instead of waiting for their own.  The empty asm pins each addition
+  // where it is written: left alone, the compiler sinks all 32 additions of a K-tile to its end (128 live registers, spilled).
+  f32x4 part[2][RH];
+  auto chain = [&](auto s_c, auto h_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value, H = decltype(h_c)::value;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int h = 0; h < TH; ++h) {
-        if constexpr (STREAM_B)
-          acc[h][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[q][PA[t]][h], fs[U & 1][PB[t]], FIRST && t == 0 ? zero : acc[h][s], 0, 0, 0);
-        else
-          acc[s][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs[U & 1][PA[t]], fh[q][PB[t]][h], FIRST && t == 0 ? zero : acc[s][h], 0, 0, 0);
-      }
+    for (int k = 0; k < 6; ++k) {
+      if constexpr (STREAM_B) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs[S & 1][PB[k]], fh[PA[k]][H], t, 0, 0, 0);
+      else t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[PB[k]][H], fs[S & 1][PA[k]], t, 0, 0, 0);
     }
+    part[S & 1][H] = t;
+  };
+  auto commit = [&](auto s_c, auto h_c, auto first_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value, H = decltype(h_c)::value;
+    f32x4& a = STREAM_B ? acc[H][S] : acc[S][H];
+    if constexpr (decltype(first_c)::value != 0) a = part[S & 1][H];
+    else a += part[S & 1][H];
+    asm volatile("" : "+v"(a));
   };
 
-  // ---- epilogue state of the tile whose accumulators are complete: stored block by block from the registers (register e of
-  //      a block is row (e & 3) + 8 (e >> 2) + 4 half, column r32: one store instruction = two 128-byte row segments), each
-  //      block just before the NEXT tile's first MFMA overwrites it — the stores drain under that tile's K loop ----
+  // ---- epilogue state of the tile whose accumulators are complete ----
   char* e_ob = nullptr;            // uniform: &out[batch][row0][col0] of the wave tile
-  int e_lim = 0;                   // per lane: rows of the wave tile inside M, minus the lane's 4 half (>= 32 TM: no masking)
+  int e_lim = 0;                   // per lane: rows of the wave tile inside M, minus the lane's row inside a block
   bool e_full = true;
-  float e_bias[TN];
+  int e_slot = 0;                  // LDS bias slot of that tile
   const float lo = p.relu ? 0.f : -__builtin_inff();
-  const uint32_t vo = (uint32_t)((4 * half * p.out_ld + r32) * 4);
+  const uint32_t vo = (uint32_t)((r16 * p.out_ld + 4 * kg) * 4);
   auto set_epilogue = [&](int n) __attribute__((always_inline)) {
-    int t = x_start + slot + n * per_x;
-    const int batch = t / nblk1;
-    t -= batch * nblk1;
-    const int tile_n = t % p.tilesN, tile_m = t / p.tilesN;
+    int batch, tile_m, tile_n;
+    tile_coords(n, batch, tile_m, tile_n);
     const long row0 = (long)tile_m * BM + wm * 32 * TM;
     const int col0 = tile_n * BN + wn * 32 * TN;
     e_ob = p.out + ((long)batch * p.bsO + row0 * p.out_ld + col0) * 4;
     const long rows = p.M - row0;
     e_full = rows >= 32 * TM;
-    e_lim = (int)(rows < 32 * TM ? rows : 32 * TM) - 4 * half;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) e_bias[j] = p.bias ? p.bias[col0 + j * 32 + r32] : 0.f;
+    e_lim = (int)(rows < 32 * TM ? rows : 32 * TM) - r16;
+    e_slot = n & 3;
   };
-  // blocks of streamed index s: (h, s) for h < TH when B streams, (s, h) when A streams
+  // blocks of streamed index S: (h, S) for h < RH when B streams, (S, h) when A streams; block (i, j) = rows 16 i .., columns 16 j ..
   auto store_blocks = [&](auto s_c) __attribute__((always_inline)) {
     constexpr int S = decltype(s_c)::value;
-    const long ld_b = p.out_ld * 4;
+    const long ld16 = p.out_ld * 64;   // bytes per 16 rows
+    const float* const sbias = reinterpret_cast<const float*>(smem + BIAS_OFF) + e_slot * BN + wn * 32 * TN + 4 * kg;
     auto body = [&](auto masked_c) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_c)::value != 0;
-      static_for<0, TH>([&](auto h_c) __attribute__((always_inline)) {
+      static_for<0, RH>([&](auto h_c) __attribute__((always_inline)) {
         constexpr int H = decltype(h_c)::value;
         constexpr int I = STREAM_B ? H : S, J = STREAM_B ? S : H;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rr = I * 32 + (e & 3) + 8 * (e >> 2);  // + 4 half per lane
-          const float v = fmaxf(acc[I][J][e] + e_bias[J], lo);
-          const char* const rowp = e_ob + rr * ld_b;        // uniform
-          if (!MASKED || rr < e_lim) store_f32_saddr<J * 128>(rowp, vo, v);
-        }
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + J * 16);
+        f32x4 v = acc[I][J] + b4;
+        v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+        const char* const rowp = e_ob + I * ld16;          // uniform
+        if (!MASKED || I * 16 < e_lim) store_f32x4_saddr<J * 64>(rowp, vo, v);
       });
     };
     if (e_full) body(ic<0>{});
@@ -363,57 +364,68 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
 
   uint32_t so = 0;                                         // byte offset of the stage being read
   int g = 0;
-  // one K-tile.  FIRST = the first of an output tile: its first TS units finish the previous tile (prev) block by block
-  auto ktile = [&](auto first_c, bool prev) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_c)::value != 0;
-    static_for<0, UNITS - 1>([&](auto u_c) __attribute__((always_inline)) {
+  // one K-tile = RS units (one streamed block x all held blocks, 6 RH MFMAs).  FIRST = the first K-tile of an output tile: unit s
+  // first stores the previous tile's blocks of streamed index s (prev), then starts them anew.  PEND_FIRST = the K-tile BEFORE
+  // this one was such a first K-tile (its last unit's partial sums are committed in this one's unit 0).
+  auto ktile = [&](auto first_c, auto pend_first_c, bool prev) __attribute__((always_inline)) {
+    constexpr int FIRST = decltype(first_c)::value;
+    static_for<0, RS - 1>([&](auto u_c) __attribute__((always_inline)) {
       constexpr int U = decltype(u_c)::value;
-      if (!(DBG & 8)) issue_reads(ic<U + 1>{}, so);
+      read_stream(ic<U + 1>{}, so);
       __builtin_amdgcn_sched_barrier(0);     // keep the reads AHEAD of this unit's MFMAs (the scheduler sinks them otherwise)
-      if constexpr (FIRST && U < TS) {
-        if constexpr (U == 0) {
-          // the bias values were requested a whole K loop ago: make the compiler wait for them HERE, before the first store — its
-          // vmcnt bookkeeping does not see the inline-asm stores, and a wait placed between two blocks' stores would drain them
-#pragma unroll
-          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(e_bias[j]));
-        }
-        if (prev && (!(DBG & 64) || p.relu == 12345)) store_blocks(ic<U>{});
+      if constexpr (FIRST != 0) {
+        if (prev) store_blocks(u_c);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!(DBG & 4)) mfma_unit(u_c, ic<(FIRST && U < TS) ? 1 : 0>{});
+      static_for<0, RH>([&](auto h_c) __attribute__((always_inline)) {
+        chain(u_c, h_c);
+        if constexpr (U > 0) commit(ic<U - 1>{}, h_c, first_c);
+        else if (FIRST == 0 || prev) commit(ic<RS - 1>{}, h_c, pend_first_c);   // the previous K-tile's last unit
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
-    // last unit: its fragments are in registers -> the stage can be handed back; the first reads of the next stage cover
-    // their latency under this unit's MFMAs
+    // last unit: its streamed fragments are in registers -> the stage can be handed back.  The next K-tile's first streamed block
+    // goes out at once; its held blocks are re-read one by one, each right behind the last MFMAs that used the old one.  (After
+    // the workgroup's last K-tile these reads fetch stale LDS bytes nobody uses: unconditional, so the loop body has no branch.)
     lds_barrier();                                         // #(g + 1)
     so ^= (uint32_t)STAGE_B;
-    if (!(DBG & 8) && g + 1 < G) issue_reads(ic<0>{}, so);
+    read_stream(ic<0>{}, so);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 4)) mfma_unit(ic<UNITS - 1>{}, ic<0>{});
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST != 0) {
+      if (prev) store_blocks(ic<RS - 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, RH>([&](auto h_c) __attribute__((always_inline)) {
+      chain(ic<RS - 1>{}, h_c);
+      commit(ic<RS - 2>{}, h_c, first_c);
+      __builtin_amdgcn_sched_barrier(0);
+      read_held(h_c, so);
+      __builtin_amdgcn_sched_barrier(0);
+    });
     ++g;
   };
 
   lds_barrier();                                           // #0
-  issue_reads(ic<0>{}, so);
-  for (int n = 0; n < my_tiles; ++n) {
-    ktile(ic<1>{}, n > 0);
+  static_for<0, RH>([&](auto h_c) __attribute__((always_inline)) { read_held(h_c, so); });
+  read_stream(ic<0>{}, so);
+  for (int n = 0; n < my_tiles; ++n) {                     // ktiles >= 2 (host check)
+    ktile(ic<1>{}, ic<0>{}, n > 0);
     set_epilogue(n);
-    for (int kt = 1; kt < p.ktiles; ++kt) ktile(ic<0>{}, false);
+    ktile(ic<0>{}, ic<1>{}, false);
+    for (int kt = 2; kt < p.ktiles; ++kt) ktile(ic<0>{}, ic<0>{}, false);
   }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(e_bias[j]));
-  if (!(DBG & 64) || p.relu == 12345) static_for<0, TS>([&](auto s_c) __attribute__((always_inline)) { store_blocks(s_c); });
+  static_for<0, RH>([&](auto h_c) __attribute__((always_inline)) { commit(ic<RS - 1>{}, h_c, ic<0>{}); });
+  static_for<0, RS>([&](auto s_c) __attribute__((always_inline)) { store_blocks(s_c); });
 }
 
-template <int TM, int TN, bool GEN, int DBG = 0, int DA_ = 2>
+template <int TM, int TN, bool GEN>
 int launch_pp(ConvParams& p, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.tilesM = (int)((p.M + BM - 1) / BM);
   p.tilesN = p.Cout / BN;
   p.ktiles = (int)(p.Ktot / 32);
-  constexpr int LDS = 2 * 3 * (BM + BN) * 64;
-  auto kern = conv_split_pp_kernel<TM, TN, GEN, DBG, DA_>;
+  constexpr int LDS = 2 * 3 * (BM + BN) * 64 + 4 * BN * 4;
+  auto kern = conv_split_pp_kernel<TM, TN, GEN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -441,37 +453,11 @@ int launch_pp(ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
-// Whether this shape has a producer / consumer instance (Cout % 128 == 0; the caller has checked Ktot % 32 == 0).
-bool msocr_internal_split_pp_takes(const ConvParams& p) { return p.Cout % 128 == 0 && !p.has_res; }
+// Whether this launch has a producer / consumer instance: Cout % 128 == 0, no residual operand, at least two K-tiles (the caller has
+// checked Ktot % 32).
+bool msocr_internal_split_pp_takes(const ConvParams& p) { return p.Cout % 128 == 0 && !p.has_res && p.Ktot >= 64; }
 
 int msocr_internal_split_pp_launch(ConvParams& p, hipStream_t s, bool general) {
-  static int dbg = -1;
-  if (dbg < 0) {
-    const char* e = getenv("MSOCR_PP_DBG");
-    dbg = e ? atoi(e) : 0;
-  }
-  if (dbg && p.Cout % 256 == 0 && !general) {
-    switch (dbg) {
-      case 1: return launch_pp<2, 4, false, 1>(p, s);
-      case 2: return launch_pp<2, 4, false, 2>(p, s);
-      case 4: return launch_pp<2, 4, false, 4>(p, s);
-      case 8: return launch_pp<2, 4, false, 8>(p, s);
-      case 10: return launch_pp<2, 4, false, 10>(p, s);
-      case 12: return launch_pp<2, 4, false, 12>(p, s);
-      case 16: return launch_pp<2, 4, false, 16>(p, s);
-      case 32: return launch_pp<2, 4, false, 32>(p, s);
-      case 64: return launch_pp<2, 4, false, 64>(p, s);
-      case 128: return launch_pp<2, 4, false, 128>(p, s);
-      case 130: return launch_pp<2, 4, false, 130>(p, s);
-      case 80: return launch_pp<2, 4, false, 80>(p, s);
-      case 96: return launch_pp<2, 4, false, 96>(p, s);
-      case 316: return launch_pp<2, 4, false, 16, 3>(p, s);
-      case 416: return launch_pp<2, 4, false, 16, 4>(p, s);
-      case 616: return launch_pp<2, 4, false, 16, 6>(p, s);
-      case 300: return launch_pp<2, 4, false, 0, 3>(p, s);
-      case 400: return launch_pp<2, 4, false, 0, 4>(p, s);
-    }
-  }
   if (p.Cout % 256 == 0) return general ? launch_pp<2, 4, true>(p, s) : launch_pp<2, 4, false>(p, s);
   if (p.Cout % 128 == 0) return general ? launch_pp<4, 2, true>(p, s) : launch_pp<4, 2, false>(p, s);
   return MSOCR_E_ARG;

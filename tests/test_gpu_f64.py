@@ -1,0 +1,79 @@
+"""f64 arbitration of the floating-point tolerances: the device's f32 path and the oracle's f32 path are BOTH
+measured against the same network evaluated in float64 on the CPU, and the device may be at most 2x as far from f64 as the
+reference's own f32 arithmetic is:   err(device, f64) <= 2 * err(oracle-f32, f64)   for the EAST score map and geometry
+(reference detectors/_east/east.py:135-139) and for the TRBA encoder output batch_H (recognizers/_trba/model/model.py:387-393).
+This replaces "2x what we measured" (tests/conftest.py GEO_RTOL) with "no worse than the reference's arithmetic": a device path
+whose error hides behind the oracle's own rounding would fail here."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from manuscript_ocr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _report(what, dev, ref32, ref64):
+    e_dev = float(np.abs(dev.astype(np.float64) - ref64).max())
+    e_ref = float(np.abs(ref32.astype(np.float64) - ref64).max())
+    scale = max(float(np.abs(ref64).max()), 1e-30)
+    print(f"f64 arbitration {what}: device {e_dev:.3e} ({e_dev / scale:.2e} of max), oracle-f32 {e_ref:.3e} ({e_ref / scale:.2e}), ratio {e_dev / max(e_ref, 1e-30):.2f}")
+    return e_dev, e_ref
+
+
+@pytest.mark.parametrize("hw,pages", [((256, 192), 2), ((1536, 2048), 1)])
+def test_east_forward_device_vs_f64_no_worse_than_2x_the_oracle_f32(hw, pages):
+    _need_gpu()
+    from manuscript_ocr_amd.detectors._east.net import EastNet
+    from oracle import east_model as oem
+    from oracle import imgproc
+    sd = synth.east_state_dict(seed=20260128)
+    net32 = oem.EASTNet()
+    net32.load_state_dict(sd)
+    net32.eval()
+    net64 = copy.deepcopy(net32).double()
+    H, W = hw
+    pg = np.stack([synth.synth_page(31 + k, H, W)[0] for k in range(pages)])
+    x = torch.from_numpy(np.concatenate([imgproc.east_preprocess(p, W, H) for p in pg]))
+    with torch.no_grad():
+        r32 = net32(x)
+        r64 = net64(x.double())
+    score, geo = EastNet(sd, torch.float32).forward(torch.from_numpy(pg).cuda())
+    torch.cuda.synchronize()
+    s32, g32 = r32["score"][:, 0].numpy(), r32["geometry"].permute(0, 2, 3, 1).numpy()
+    s64, g64 = r64["score"][:, 0].numpy(), r64["geometry"].permute(0, 2, 3, 1).numpy()
+    es_d, es_r = _report(f"EAST {hw} score", score.cpu().numpy(), s32, s64)
+    eg_d, eg_r = _report(f"EAST {hw} geometry", geo.cpu().numpy(), g32, g64)
+    assert es_d <= 2.0 * es_r, (es_d, es_r)
+    assert eg_d <= 2.0 * eg_r, (eg_d, eg_r)
+
+
+def test_trba_batch_H_device_vs_f64_no_worse_than_2x_the_oracle_f32():
+    _need_gpu()
+    from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
+    from oracle import trba_model as otm
+    sd = synth.trba_state_dict(194, 256, seed=5)
+    net32 = otm.TRBANet(194, 256)
+    net32.load_state_dict(sd, strict=True)
+    net32.eval()
+    net64 = copy.deepcopy(net32).double()
+    canv = synth.synth_crops(9, 32, 32, 100)
+    x = torch.from_numpy(((canv.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
+    with torch.no_grad():
+        f32_, f64_ = net32.cnn(x).permute(0, 2, 3, 1).numpy(), net64.cnn(x.double()).permute(0, 2, 3, 1).numpy()
+        h32, h64 = net32.encode(x).numpy(), net64.encode(x.double()).numpy()
+    net = TrbaNet(sd, 194, 256, torch.float32)
+    cd = torch.from_numpy(canv).cuda()
+    f_dev = net.cnn(cd).float().cpu().numpy()
+    h_dev = net.encode(cd)[0].float().cpu().numpy()
+    ef_d, ef_r = _report("TRBA SE-ResNet31 features (32 crops)", f_dev.reshape(f64_.shape), f32_, f64_)
+    eh_d, eh_r = _report("TRBA batch_H (32 crops)", h_dev, h32, h64)
+    assert ef_d <= 2.0 * ef_r, (ef_d, ef_r)
+    assert eh_d <= 2.0 * eh_r, (eh_d, eh_r)

@@ -240,6 +240,32 @@ def test_device_batches_never_split_a_reference_chunk():
     assert TRBA._device_batches(big, 40, [(0, 40)], 32)[0] == [(0, 32), (32, 40)]
 
 
+def test_no_packed_f32_valu_beside_mfma(tmp_path):
+    """Every translation unit the Makefile lists in NOPK_OBJS (kernels that run beside bf16 MFMAs) must contain NO packed-f32 VALU
+    instruction: v_pk_fma_f32 with op_sel returns wrong low results in lanes 48..63 beside v_mfma_f32_32x32x16_bf16
+    (tools/microbench/pk_fma_beside_mfma.hip, profiles/r04_pk_fma_probe.txt) and any packed f32 op there costs matrix-pipe time
+    (profiles/r04_pp_ablations.txt).  Checked on the BUILT objects: the device code object is unbundled and disassembled."""
+    import re
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "manuscript_ocr_amd", "csrc")
+    bundler, objdump = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        pytest.skip("ROCm binutils not present")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    objs = re.search(r"^NOPK_OBJS = (.*)$", mk, re.M).group(1).split()
+    assert {"attn_beam_mfma.o", "conv_split_pp.o", "conv_split.o", "bilstm_mfma.o"} <= set(objs)
+    subprocess.check_call(["make", "-s", "-j4", "-C", csrc, "ARCH=gfx950"])   # no-op when built
+    for o in objs:
+        fat, co = str(tmp_path / (o + ".fat")), str(tmp_path / (o + ".co"))
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", os.path.join(csrc, o), fat])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+        asm = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        assert "s_endpgm" in asm, o
+        packed = re.findall(r"v_pk_(?:fma|add|mul)_f32[^\n]*", asm)
+        assert not packed, f"{o}: {len(packed)} packed-f32 VALU instructions, e.g. {packed[0]}"
+
+
 def test_oracle_is_only_a_checker():
     """The CPU restatement under oracle/ is test infrastructure: the product package never imports it, bench.py only inside
     its cpu_baseline leg (cpu_baseline and the cpu_baseline_* helpers only it calls), __graft_entry__ only inside smoke()."""

@@ -1,15 +1,16 @@
 #!/bin/bash
 # dev: the packed-f32 fault of the hoisted context sum (csrc/attn_beam_mfma.hip, note at add_np / fmac_np), reproduced on purpose:
-# the kernel built with the sum in the form the compiler pairs into v_pk_fma_f32 (-DMSOCR_ATTN_PACKED_SUM), with and without a
-# workgroup barrier between the sum and the bf16 MFMA loop (-DMSOCR_ATTN_SUM_BARRIER), against the exact-f32 kernel of the product
-# library: rows of every beam's step-1 logits off by more than 1e-4.   gpurun -- bash tools/attn_packed_probe.sh
+# the kernel built as the product builds it (no packed-f32 instructions: csrc/Makefile NOPK), then WITH them — the compiler pairs the
+# sum into v_pk_fma_f32 ... op_sel:[0,1,0] — with and without a workgroup barrier between the sum and the bf16 MFMA loop
+# (-DMSOCR_ATTN_SUM_BARRIER), against the exact-f32 kernel of the product library: rows of every beam's step-1 logits off by more
+# than 1e-4.  The instruction-level reproducer is tools/microbench/pk_fma_beside_mfma.hip.   gpurun -- bash tools/attn_packed_probe.sh
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R/manuscript_ocr_amd/csrc
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -shared attn_beam_mfma.hip trba_kernels.hip attn_general.hip"
-/opt/rocm/bin/hipcc $F -o /tmp/libattn_v0.so &
-/opt/rocm/bin/hipcc $F -DMSOCR_ATTN_PACKED_SUM -o /tmp/libattn_v1.so &
-/opt/rocm/bin/hipcc $F -DMSOCR_ATTN_PACKED_SUM -DMSOCR_ATTN_SUM_BARRIER -o /tmp/libattn_v2.so &
+/opt/rocm/bin/hipcc $F -Xclang -target-feature -Xclang -packed-fp32-ops -o /tmp/libattn_v0.so 2> >(grep -v "not a recognized feature" >&2) &
+/opt/rocm/bin/hipcc $F -o /tmp/libattn_v1.so &
+/opt/rocm/bin/hipcc $F -DMSOCR_ATTN_SUM_BARRIER -o /tmp/libattn_v2.so &
 wait
 cd $R
 python3 - <<PY
@@ -28,7 +29,7 @@ def run(mode):
     torch.cuda.synchronize()
     return ws[: 4 * B * S * K * V].view(torch.float32).view(B, S, K, V).clone()
 ref = run("0")
-names = {0: "one-register FMAs (the product form)", 1: "packed sum", 2: "packed sum + barrier before the MFMA loop"}
+names = {0: "product build (no packed-f32 instructions)", 1: "packed sum", 2: "packed sum + barrier before the MFMA loop"}
 for v in (0, 1, 2):
     L = ctypes.CDLL(f"/tmp/libattn_v{v}.so")
     for name in ("msocr_attn_beam", "msocr_attn_beam_hoisted"):

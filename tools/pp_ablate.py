@@ -6,8 +6,9 @@ import torch
 from manuscript_ocr_amd import ops
 
 def run(M, N, K, iters=8):
-    x = torch.randn(1, M, 1, K, device="cuda")
-    w = ops.attach_split(torch.randn(N, 1, 1, K, device="cuda") * 0.05, True)
+    z = os.environ.get("MSOCR_ZERO", "0")   # 1: zero activations, 2: zero weights, 3: both (DVFS probe: zero operands draw less power)
+    x = torch.randn(1, M, 1, K, device="cuda") * (0.0 if z in ("1", "3") else 1.0)
+    w = ops.attach_split(torch.randn(N, 1, 1, K, device="cuda") * (0.0 if z in ("2", "3") else 0.05), True)
     out = ops.conv2d(x, w, None)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,5 +22,5 @@ def run(M, N, K, iters=8):
 
 if __name__ == "__main__":
     shapes = [(161280, 512, 512), (161280, 512, 4096), (161280, 256, 256), (393216, 128, 512)]
-    print("DBG", os.environ.get("MSOCR_PP_DBG", "0"), "PP", os.environ.get("MSOCR_SPLIT_PP", "1"),
+    print("ZERO", os.environ.get("MSOCR_ZERO", "0"), "PP", os.environ.get("MSOCR_SPLIT_PP", "1"),
           " ".join(f"{M}x{N}x{K}: {run(M, N, K):.1f}" for (M, N, K) in shapes), flush=True)
