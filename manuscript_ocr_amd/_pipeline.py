@@ -168,7 +168,9 @@ class Pipeline:
 
     def predict_batch(self, images: List[Union[str, np.ndarray]], recognize_text: bool = True, profile: bool = False,
                       pages_dev=None, sub_batches: int = 0, _maps_override=None):
-        """Equally sized pages -> list of Pages, same results as per-page `predict`.
+        """Pages -> list of Pages, same results as per-page `predict`.  Pages of different sizes are processed as one group per
+        size (the word crops are cut from the ORIGINAL pages, which only stack when they are equally sized; the detector alone
+        batches any mix: EAST.predict_batch), results returned in input order.
 
         MI355X fast path (detector and recogniser are this package's EAST / TRBA): the pages are uploaded once,
         word crops are cut, resized and padded ON THE DEVICE from the resident pages (no host crop, no per-crop upload)
@@ -181,7 +183,38 @@ class Pipeline:
         native = isinstance(self.detector, EAST) and isinstance(self.recognizer, TRBA)
         if not native:
             return [self.predict(im, recognize_text=recognize_text, profile=profile) for im in images]
+        if pages_dev is None and len(images) > 1:
+            shapes = [self._shape_of(im) for im in images]
+            if len(set(shapes)) > 1:
+                # ragged batch: every size group's detector work is enqueued before the first group is collected
+                groups = {}
+                for i, sh in enumerate(shapes):
+                    groups.setdefault(sh, []).append(i)
+                def maps_of(idx):  # injected maps (tests / benchmarks) follow their pages
+                    if _maps_override is None:
+                        return None
+                    import torch
+                    sel = torch.tensor(idx, device=_maps_override[0].device)
+                    return (_maps_override[0].index_select(0, sel), _maps_override[1].index_select(0, sel))
+                handles = [(idx, self.submit_batch([images[i] for i in idx], recognize_text, profile, None, sub_batches, maps_of(idx)))
+                           for idx in groups.values()]
+                out = [None] * len(images)
+                for idx, h in handles:
+                    for i, pg in zip(idx, self.collect_batch(h)):
+                        out[i] = pg
+                return out
         return self.collect_batch(self.submit_batch(images, recognize_text, profile, pages_dev, sub_batches, _maps_override))
+
+    @staticmethod
+    def _shape_of(im):
+        """(height, width) of a page without decoding it twice: arrays know theirs, files are asked through PIL's header parse."""
+        if isinstance(im, np.ndarray):
+            return tuple(im.shape[:2])
+        try:
+            with Image.open(im) as f:
+                return (f.height, f.width)
+        except Exception:
+            return tuple(read_image(im).shape[:2])
 
     def submit_batch(self, images, recognize_text: bool = True, profile: bool = False, pages_dev=None, sub_batches: int = 0,
                      _maps_override=None):

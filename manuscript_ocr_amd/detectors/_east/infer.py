@@ -114,13 +114,21 @@ class EAST:
         q = max(1, int(self.quantization))
         return max(1, (th // 4 // q) * (tw // 4 // q))
 
-    def detect_device(self, pages_dev: torch.Tensor, maps_override=None):
+    def detect_device(self, pages_dev, maps_override=None):
         """pages_dev [N,h,w,3] u8 on the device (any size) -> device tensors
-        (score, geo, boxes [N,max_cand,9], nbox [N]).  Resize, network, decode and LANMS, all HIP."""
+        (score, geo, boxes [N,max_cand,9], nbox [N]).  Resize, network, decode and LANMS, all HIP.
+        A LIST of [h_i,w_i,3] tensors is a ragged batch: the reference resizes every page to the network input first
+        (infer.py:304), so pages of any mix of sizes are resized on the device one by one, stacked and sent through the network
+        together; only the box tail, which scales back to each page's own size, runs per size group."""
         tw, th = self._target_wh()
-        oh, ow = int(pages_dev.shape[1]), int(pages_dev.shape[2])
-        if pages_dev.shape[1] != th or pages_dev.shape[2] != tw:
-            pages_dev = ops.resize_linear_u8(pages_dev, th, tw)
+        if isinstance(pages_dev, (list, tuple)):
+            sizes = [(int(t.shape[0]), int(t.shape[1])) for t in pages_dev]
+            pages_dev = torch.cat([t[None] if sizes[i] == (th, tw) else ops.resize_linear_u8(t[None].contiguous(), th, tw)
+                                   for i, t in enumerate(pages_dev)])
+        else:
+            sizes = [(int(pages_dev.shape[1]), int(pages_dev.shape[2]))] * int(pages_dev.shape[0])
+            if sizes and sizes[0] != (th, tw):
+                pages_dev = ops.resize_linear_u8(pages_dev, th, tw)
         score, geo = self.model.forward(pages_dev)
         if maps_override is not None:  # benchmark / parity harness: injected maps (SURVEY.md §8d)
             score.copy_(maps_override[0], non_blocking=True)
@@ -131,9 +139,19 @@ class EAST:
         fboxes = fn = None
         if getattr(self, "device_tail", True):
             # infer.py:340-356 on the device: expand, scale back to the page, contained boxes, area anomalies, axis-aligned
-            fboxes, fn = ops.east_box_tail(boxes, nbox, self.expand_ratio_w, self.expand_ratio_h, ow / tw, oh / th,
-                                           self.axis_aligned_output, self.remove_area_anomalies, self.anomaly_sigma_threshold,
-                                           self.anomaly_min_box_count)
+            def tail(b, n, hw):
+                return ops.east_box_tail(b, n, self.expand_ratio_w, self.expand_ratio_h, hw[1] / tw, hw[0] / th,
+                                         self.axis_aligned_output, self.remove_area_anomalies, self.anomaly_sigma_threshold,
+                                         self.anomaly_min_box_count)
+            if len(set(sizes)) <= 1:
+                fboxes, fn = tail(boxes, nbox, sizes[0])
+            else:  # one launch per page size, results back in page order
+                fboxes, fn = torch.empty_like(boxes), torch.empty_like(nbox)
+                for hw in sorted(set(sizes)):
+                    idx = torch.tensor([i for i, s_ in enumerate(sizes) if s_ == hw], device=boxes.device)
+                    fb, fc = tail(boxes.index_select(0, idx).contiguous(), nbox.index_select(0, idx).contiguous(), hw)
+                    fboxes.index_copy_(0, idx, fb)
+                    fn.index_copy_(0, idx, fc)
         return score, geo, boxes, nbox, counts, fboxes, fn
 
     def _host_tail(self, quads: np.ndarray, orig_hw) -> np.ndarray:
@@ -182,7 +200,7 @@ class EAST:
         the graph's private pool until `detect_finish` has read them.  The first call of a shape runs eagerly (lazy
         one-time kernel attributes must not fall into a capture); an instance still in flight is never replayed — a
         second one is captured (two batches in flight = two instances per group)."""
-        if not self.use_graphs or ops.PROFILE is not None:
+        if not self.use_graphs or ops.PROFILE is not None or isinstance(pages_dev, (list, tuple)):
             return self.detect_device(pages_dev, maps_override) + (None,)
         key = (tuple(pages_dev.shape), None if maps_override is None else (maps_override[0].data_ptr(), maps_override[1].data_ptr()))
         pool = self._graphs.setdefault(key, {"warm": False, "inst": []})
@@ -255,15 +273,12 @@ class EAST:
                 t = ingest.read_image_device(im, self.device)  # JPEG file: decoded on the device, the host keeps only the shape
             imgs.append(np.broadcast_to(np.uint8(0), tuple(t.shape)) if t is not None else read_image(im))
             decoded.append(t)
-        if len({im.shape for im in imgs}) != 1:
-            raise ValueError("predict_batch needs equally sized pages")
         if _pages_dev is not None:
             pages = _pages_dev
-        elif all(t is not None for t in decoded):
-            pages = torch.stack(decoded)
         else:
-            pages = torch.stack([t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-                                 for t, a in zip(decoded, imgs)])
+            pages = [t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for t, a in zip(decoded, imgs)]
+            if len({im.shape for im in imgs}) == 1:
+                pages = torch.stack(pages)  # equally sized pages: one tensor (hipGraph path, one resize launch); else a ragged list
         return self.detect_finish(self.detect_start(pages, _maps_override), imgs, vis, profile, return_maps, sort_reading_order)
 
     def predict(self, img_or_path: Union[str, Path, np.ndarray], vis: bool = False, profile: bool = False,

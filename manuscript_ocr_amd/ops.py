@@ -14,7 +14,8 @@ from . import _native as nat
 
 # When set to a list, the wrappers below append one record per kernel launch: (start_event, end_event, kind, work, tag), with
 # the events recorded on the launch stream (torch's current stream).  bench.py turns them into the live HIP-event rooflines.
-#   kind "conv_gemm": work = (algorithmic direct-convolution FLOP, FLOP the MFMAs execute), tag = (M, N, K, "direct"|"winograd")
+#   kind "conv_gemm": work = (algorithmic direct-convolution FLOP, FLOP the MFMAs execute, direct-form layer bytes: input + output
+#                     (+ residual) + weights at the tensor dtype), tag = (M, N, K, "direct"|"winograd")
 #   kind "wino_in" / "wino_out" / "se_residual" / "maxpool" / ...: work = algorithmic HBM bytes (bytes in + bytes out)
 #   kind "bilstm" / "attn_beam": work = (algorithmic bytes per SURVEY.md 8d, recurrent steps of the launch)
 PROFILE = None
@@ -245,7 +246,8 @@ def _conv3x3_fused64(x, w, u42, bias, relu, residual, pool2, out):
             _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + 24 * mt * Cin), (mt, Cin))
             e = _prof_begin()
             nat.check(f_gemm(ctypes.byref(d), u42.data_ptr(), ws.data_ptr(), bp, rp_, op, _stream()), what)
-            _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 24 * mt * Cin * Cout), (nn * H * W, Cout, 9 * Cin, name))
+            io = x.element_size() * (nn * H * W * Cin + nn * (H * W // (4 if pool2 else 1)) * Cout * (2 if residual is not None else 1) + Cout * 9 * Cin)
+            _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * 24 * mt * Cin * Cout, io), (nn * H * W, Cout, 9 * Cin, name))
     return out
 
 
@@ -329,7 +331,8 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
                 _prof_end(e, "wino_in", 4.0 * (nn * H * W * Cin + v_el), (mt, Cin))
                 e = _prof_begin()
                 nat.check(st_gemm(ctypes.byref(d), u.data_ptr(), ws.data_ptr(), _stream()), what)
-                _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * npts * mt * Cin * Cout), (nn * Ho * Wo, Cout, KH * KW * Cin, name))
+                io = x.element_size() * (nn * H * W * Cin + nn * Ho * Wo * Cout * (2 if residual is not None else 1) + Cout * KH * KW * Cin)
+                _prof_end(e, "conv_gemm", (alg * nn / N, 2.0 * npts * mt * Cin * Cout, io), (nn * Ho * Wo, Cout, KH * KW * Cin, name))
                 e = _prof_begin()
                 nat.check(st_out(ctypes.byref(d), ws.data_ptr(), bp, rp_, op, _stream()), what)
                 _prof_end(e, "wino_out", 4.0 * (m_el + nn * Ho * Wo * Cout * (2 if residual is not None else 1)), (mt, Cout))
@@ -350,7 +353,8 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
         else:
             rc = nat.lib().msocr_conv2d(ctypes.byref(d), x.data_ptr(), w.data_ptr(), bp, rp, out.data_ptr(), _stream())
             nat.check(rc, f"msocr_conv2d {tuple(x.shape)} * {tuple(w.shape)}")
-        _prof_end(e, "conv_gemm", (alg, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin),
+        io = x.element_size() * (N * H * W * Cin + N * Ho * Wo * Cout * (2 if residual is not None else 1) + Cout * KH * KW * Cin)
+        _prof_end(e, "conv_gemm", (alg, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, io),
                   (N * Ho * Wo, Cout, KH * KW * Cin, "direct_split" if split else "direct"))
     return out
 

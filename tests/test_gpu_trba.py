@@ -188,6 +188,7 @@ def _assert_near_tie_parity(rep, N, what, cal, got=None, mode=None):
     measured size)."""
     from conftest import admit_encoder_sensitive, compare_decodes
     admitted = []
+    decoder_identical = False
     if got is not None:
         ids, trun, lg = got
         rep_dec = compare_decodes(ids, trun, lg, cal["rows_on_dev_H"], mode, logit_rtol=DECODER_LOGIT_RTOL)
@@ -196,6 +197,7 @@ def _assert_near_tie_parity(rep, N, what, cal, got=None, mode=None):
         print(msg_d)
         assert not rep_dec["hard"] and len(rep_dec["ties"]) <= 1 + (3 * N) // 100, msg_d
         rep["hard"], admitted = admit_encoder_sensitive(rep, rep_dec)
+        decoder_identical = len(rep_dec["same"]) == N
     msg = (f"{what}: {len(rep['same'])}/{N} rows identical, ties {rep['ties']}, encoder-sensitive rows {admitted}, run-length-only rows "
            f"{rep['run_length_only']}, hard {rep['hard']}, max logit err {rep['max_logit_err_rel']:.2e} of max|logit|")
     print(msg)
@@ -217,10 +219,12 @@ def _assert_near_tie_parity(rep, N, what, cal, got=None, mode=None):
         slack = err - (np.asarray(cal["oracle_on_dev_H"]) + DECODER_LOGIT_RTOL)
         assert slack.max() <= 0, (what, int(slack.argmax()), float(slack.max()))
     # the response itself against the noise model (Gaussian perturbation of the measured per-row size): the median always; the 90th
-    # percentile and the maximum where the sample carries them (>= 128 rows: below that p90 rests on a handful of rows — the 48-row
-    # beam-16 case measured 3.8e-4 against 2 x 1.4e-4 with device and oracle-on-device-batch_H agreeing to three digits)
+    # percentile and the maximum for every case in which the DECODER-ONLY comparison above has at least one differing row.  When
+    # the device's decode is row-for-row identical to the oracle's decoder on the device's own batch_H, every bit of `err` is the
+    # reference decoder's own response to the encoder's in-tolerance error (the per-row triangle bound above already holds it to
+    # that response), and its upper quantiles against a Gaussian noise model carry nothing about the device — no gate on N.
     assert q(err, .5) <= cal["p50"], (what, q(err, .5), cal["p50"])
-    if N >= 128:
+    if not decoder_identical:
         assert q(err, .9) <= cal["p90"] and err.max() <= cal["max"], (what, q(err, .9), err.max(), cal["p90"], cal["max"])
 
 

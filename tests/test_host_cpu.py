@@ -145,6 +145,48 @@ def test_gather_records_world2_gloo(tmp_path):
     assert recs[5]["text"] == "стр5 — ok"
 
 
+WORKER8 = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["REPO"])
+import torch, torch.distributed as dist
+torch.set_num_threads(1)
+from manuscript_ocr_amd.dist import shard_range, gather_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n_pages = int(os.environ["N_PAGES"])
+lo, hi = shard_range(n_pages, rank, world)
+# page 2 has no words at all; with 5 pages over 8 ranks, ranks 5..7 own no page: zero records, a zero-length payload "[]"
+local = [{"page": p, "word": k, "text": "p%d/w%d é" % (p, k)} for p in range(lo, hi) for k in range(0 if p == 2 else 1 + p % 3)]
+allr = gather_records(local, torch.device("cpu"))
+if rank == 0:
+    print("RESULT" + json.dumps({"recs": allr, "spans": [shard_range(n_pages, r, world) for r in range(world)]}, ensure_ascii=False))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_pages", [13, 5])
+def test_gather_records_world8_gloo_uneven_and_empty_ranks(tmp_path, n_pages):
+    """SURVEY 8(e) at the node's width: 8 CPU ranks over gloo, a page count not divisible by 8 (13) and fewer pages than ranks (5:
+    three ranks contribute ZERO records, one page has no words) — the padded all_gather must size itself from max(sizes, 1), and the
+    gathered records must come back in GLOBAL page order (rank order = page order because the shards are contiguous)."""
+    import json
+    script = tmp_path / "w8.py"
+    script.write_text(WORKER8)
+    port = str(29741 + n_pages)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="8", N_PAGES=str(n_pages), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0][len("RESULT"):])
+    want = [(p, k) for p in range(n_pages) for k in range(0 if p == 2 else 1 + p % 3)]
+    assert [(r["page"], r["word"]) for r in res["recs"]] == want
+    assert res["recs"][0]["text"] == "p0/w0 é"
+    sizes = [b - a for a, b in res["spans"]]
+    assert sum(sizes) == n_pages and max(sizes) - min(sizes) <= 1 and (n_pages >= 8 or sizes.count(0) == 8 - n_pages)
+
+
 def test_vectorised_glue_equals_literal_restatement_on_random_boxes():
     """The host fast paths (vectorised resolve_intersections, running-sum line grouping, dict re-match) against the
     oracle's literal restatement of the reference loops, on random overlapping boxes incl. duplicates."""

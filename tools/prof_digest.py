@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_STAGE = ("conv_split_kernel", "conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+CONV_STAGE = ("conv_split_kernel", "conv_split_pp_kernel", "conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
 def one(pattern):
@@ -77,9 +77,9 @@ def main():
         gui = pmc(mfma, "GRBM_GUI_ACTIVE")
         mm = {}
         for n in busy:
-            if n.startswith(("conv_split_kernel", "conv_igemm_kernel", "wino_gemm4_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel")) and gui[n][1] > 0:
+            if n.startswith(("conv_split_kernel", "conv_split_pp_kernel", "conv_igemm_kernel", "wino_gemm4_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel")) and gui[n][1] > 0:
                 # FLOP per busy cycle and SIMD: 64 for exact-f32 MFMA, 1024 for the bf16 MFMAs of the split-operand kernels
-                fpc = 1024.0 if (n.startswith(("conv_split_kernel", "wino42_fused64_v2_kernel")) or (n.startswith("wino42_fused64_kernel") and n.rstrip(">").endswith("true"))) else 64.0
+                fpc = 1024.0 if (n.startswith(("conv_split_kernel", "conv_split_pp_kernel", "wino42_fused64_v2_kernel")) or (n.startswith("wino42_fused64_kernel") and n.rstrip(">").endswith("true"))) else 64.0
                 mm[n] = {"dispatches": busy[n][0], "SQ_VALU_MFMA_BUSY_CYCLES": busy[n][1], "GRBM_GUI_ACTIVE_sum_8xcd": gui[n][1],
                          "kernel_ns": gui[n][2],
                          "mfma_pipe_busy_fraction": busy[n][1] / (gui[n][1] / 8.0 * 1024.0),   # 1024 SIMDs, GUI summed over 8 XCDs
