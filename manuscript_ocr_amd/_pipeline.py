@@ -196,10 +196,12 @@ class Pipeline:
                     import torch
                     sel = torch.tensor(idx, device=_maps_override[0].device)
                     return (_maps_override[0].index_select(0, sel), _maps_override[1].index_select(0, sel))
-                handles = [(idx, self.submit_batch([images[i] for i in idx], recognize_text, profile, None, sub_batches, maps_of(idx)))
-                           for idx in groups.values()]
+                handles = []
+                for idx in groups.values():
+                    mo = maps_of(idx)  # kept alive in `handles` until the group is collected: the detector streams read it asynchronously
+                    handles.append((idx, self.submit_batch([images[i] for i in idx], recognize_text, profile, None, sub_batches, mo), mo))
                 out = [None] * len(images)
-                for idx, h in handles:
+                for idx, h, _mo in handles:
                     for i, pg in zip(idx, self.collect_batch(h)):
                         out[i] = pg
                 return out

@@ -171,7 +171,9 @@ def test_checkpoint_files_load_like_the_reference(gpu, tmp_path):
 
 def test_empty_and_ragged_inputs(gpu):
     """No pixel above threshold -> empty Page, recogniser untouched; empty crop list -> []; unequal page sizes in one
-    batch -> ValueError; a page whose single box is below min_text_size is detected but not recognised, like the reference."""
+    batch are processed (one group per size since round 4: test_ragged_page_batches_equal_per_page_calls) while a stacked
+    pages_dev tensor that contradicts the images still raises; a page whose single box is below min_text_size is detected but not
+    recognised, like the reference."""
     from manuscript_ocr_amd import Pipeline, synth
     from manuscript_ocr_amd.detectors import EAST
     from manuscript_ocr_amd.recognizers import TRBA
@@ -184,8 +186,10 @@ def test_empty_and_ragged_inputs(gpu):
     out = pipe.predict_batch(pages, _maps_override=zero)
     assert [len(p.blocks[0].words) for p in out] == [0, 0] and pipe.get_text(out[0]) == ""
     assert rec.predict([]) == []
+    out2 = pipe.predict_batch([pages[0], pages[1][:64]])   # ragged: two size groups, no words either (random weights)
+    assert len(out2) == 2 and all(len(p.blocks) == 1 for p in out2)
     with pytest.raises(ValueError):
-        pipe.predict_batch([pages[0], pages[1][:64]])
+        pipe.submit_batch([pages[0], pages[1][:64]])       # the equal-size stage itself still refuses a mix
     # one thin quad: detected, but below min_text_size -> no recognition (text stays None)
     score = torch.zeros(1, H // 4, W // 4, device="cuda")
     geo = torch.zeros(1, H // 4, W // 4, 8, device="cuda")
