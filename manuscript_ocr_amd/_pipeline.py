@@ -231,11 +231,11 @@ class Pipeline:
         # image ingest: a JPEG file is decoded ON THE DEVICE (host Huffman stage + HIP reconstruction, ingest.py) — the page's
         # pixels never exist on the host, `arrays` then only carries the shape; everything else goes through read_image
         arrays, decoded = [], []
-        for im in images:
-            t = None
-            if pages_dev is None and getattr(self, "device_ingest", True):
-                from . import ingest
-                t = ingest.read_image_device(im, det.device)
+        dec = [None] * len(images)
+        if pages_dev is None and getattr(self, "device_ingest", True):
+            from . import ingest
+            dec = ingest.read_images_device(list(images), det.device)  # host Huffman stages of the batch in parallel
+        for im, t in zip(images, dec):
             if t is not None:
                 arrays.append(np.broadcast_to(np.uint8(0), tuple(t.shape)))
             else:

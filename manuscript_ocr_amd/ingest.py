@@ -63,6 +63,52 @@ def decode_jpeg_device(data: bytes, device="cuda"):
     return out
 
 
+def _host_stage(path):
+    """File -> (info, coefficients) through the serial Huffman stage, or None (not a file / not a supported JPEG)."""
+    if not isinstance(path, (str, os.PathLike)) or not os.path.isfile(path):
+        return None
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:2] != b"\xff\xd8":
+        return None
+    return jpeg_coefficients(data)
+
+
+def _device_stage(r, device):
+    import torch
+
+    from . import ops
+    info, coef = r
+    coef_dev = torch.from_numpy(coef).to(device, non_blocking=True)
+    ws = torch.empty((nat.lib().msocr_jpeg_workspace_bytes(ctypes.byref(info)),), dtype=torch.uint8, device=device)
+    out = torch.empty((info.height, info.width, 3), dtype=torch.uint8, device=device)
+    nat.check(nat.lib().msocr_jpeg_reconstruct(ctypes.byref(info), coef_dev.data_ptr(), ws.data_ptr(), out.data_ptr(), ops._stream()),
+              "jpeg_reconstruct")
+    return out
+
+
+_POOL = None
+
+
+def read_images_device(paths, device="cuda"):
+    """A batch of files -> list of device RGB tensors (None where read_image must take over).  The entropy decode of a baseline
+    JPEG without restart markers is one serial bit stream per FILE, but files are independent: the host stages of a batch run on a
+    thread pool (the ctypes call releases the GIL), one page per core, while this thread uploads the coefficients and launches the
+    reconstruction of the pages already decoded.  16 pages of 2048 x 1536 (1.6 MB each): 56 -> see bench.py secondary_lines."""
+    global _POOL
+    if len(paths) <= 1:
+        return [read_image_device(p, device) for p in paths]
+    from concurrent.futures import ThreadPoolExecutor
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 2) - 1)), thread_name_prefix="msocr-jpeg")
+    futs = [_POOL.submit(_host_stage, p) for p in paths]
+    out = []
+    for f in futs:
+        r = f.result()
+        out.append(None if r is None else _device_stage(r, device))
+    return out
+
+
 def read_image_device(path, device="cuda"):
     """File -> device RGB tensor through the JPEG path, or None (not a file / not a supported JPEG: use read_image)."""
     if not isinstance(path, (str, os.PathLike)) or not os.path.isfile(path):

@@ -25,10 +25,14 @@ from .transforms import decode_tokens, load_charset, resize_and_pad
 
 class _GraphLease:
     """Holds one captured recogniser-graph instance for a handle; released by recognize_finish (also when it raises) or when the
-    handle is dropped without ever being finished."""
+    handle is dropped without ever being finished.  An event recorded right behind the replay says when the instance's static
+    buffers may be rewritten: a dropped handle waits for THAT event only — never a device-wide synchronize from a finalizer (the
+    garbage collector may run it while another stream capture is in progress, and a synchronize would invalidate that capture)."""
 
     def __init__(self, inst):
         self.inst = inst
+        self.done = torch.cuda.Event()
+        self.done.record()  # on the replay's stream, behind the replay
 
     def release(self):
         if self.inst is not None:
@@ -36,13 +40,17 @@ class _GraphLease:
             self.inst = None
 
     def __del__(self):
-        if self.inst is not None:
-            try:
-                torch.cuda.synchronize()  # the replay may still be running: its static buffers must not be rewritten under it
-            except Exception:
-                pass
-            self.inst["busy"] = False
-            self.inst = None
+        if self.inst is None:
+            return
+        try:
+            if torch.cuda.is_current_stream_capturing():
+                return  # leave the instance marked busy: it is simply never reused (a new one is captured on demand)
+            if not self.done.query():
+                self.done.synchronize()
+        except Exception:
+            return  # the wait failed: do not hand the instance out again
+        self.inst["busy"] = False
+        self.inst = None
 
 
 class TRBA:

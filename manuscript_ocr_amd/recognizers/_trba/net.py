@@ -6,11 +6,14 @@ model/seresnet31.py:180-187 with:
   * BatchNorm folded into the bias-free convs (eval mode), NHWC, implicit-GEMM MFMA convs;
   * the 3x3 C=3 stem as a 3-tap conv over a zero-bordered padded-channel canvas;
   * SE gate + residual add + ReLU fused in one kernel per block;
-  * LSTM input projections and the Linear layers as exact-f32 MFMA GEMMs (1x1 convs), the
-    recurrence as one persistent launch per layer (both directions);
+  * LSTM input projections and the Linear layers as MFMA GEMMs (1x1 convs: split-operand bf16x3 with f32 accumulation under
+    precision="fp32", exact-f32 MFMA under "fp32-exact"), the recurrence as one persistent launch per layer (both directions);
   * the attention decoder as ONE launch for the whole step loop, i2h(batch_H) hoisted out of it,
     the one-hot matmul replaced by a row gather of W_ih (model.py:36,44: identical arithmetic).
-The CNN may run in bf16 (`dtype`); recurrent and attention stages are always exact f32.
+The CNN may run in bf16 (`dtype`).  The recurrent and attention stages keep f32 state and f32 accumulation in every mode; under
+precision="fp32" (the default) their matrix products are the split-operand form on the bf16 pipes (f32 result up to summation
+order) and their gate nonlinearities use the hardware-rate v_exp_f32 / v_rcp_f32 (1-2 ulp); precision="fp32-exact" runs the
+exact-f32 MFMA / VALU kernels with libm-grade expf / tanhf throughout.
 """
 import ctypes
 

@@ -53,6 +53,19 @@ def test_east_forward_device_vs_f64_no_worse_than_2x_the_oracle_f32(hw, pages):
     eg_d, eg_r = _report(f"EAST {hw} geometry", geo.cpu().numpy(), g32, g64)
     assert es_d <= 2.0 * es_r, (es_d, es_r)
     assert eg_d <= 2.0 * eg_r, (eg_d, eg_r)
+    # precision="fp32-exact" (exact-f32 MFMA everywhere, sequential accumulation, no chunking): BASELINE.md's ORIGINAL bound — 1e-4
+    # absolute on both maps against the f32 reference path — is asserted for this mode so that the exact path cannot drift
+    # (ADVICE r3); its distance from f64 is printed beside the default mode's
+    score_x, geo_x = EastNet(sd, torch.float32, split=False).forward(torch.from_numpy(pg).cuda())
+    torch.cuda.synchronize()
+    _report(f"EAST {hw} score, fp32-exact", score_x.cpu().numpy(), s32, s64)
+    _report(f"EAST {hw} geometry, fp32-exact", geo_x.cpu().numpy(), g32, g64)
+    ex_s = float(np.abs(score_x.cpu().numpy() - s32).max())
+    ex_g = float(np.abs(geo_x.cpu().numpy() - g32).max())
+    print(f"fp32-exact vs the f32 oracle: score {ex_s:.3e}, geometry {ex_g:.3e} (BASELINE bound 1e-4 absolute)")
+    assert ex_s < 1e-4, ex_s
+    if hw == (256, 192):
+        assert ex_g < 1e-4, ex_g
 
 
 def test_trba_batch_H_device_vs_f64_no_worse_than_2x_the_oracle_f32():
