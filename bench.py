@@ -651,6 +651,21 @@ def main():
                 "ms_at_bench_run_length": att["avg_launch_ms"] if att else None,
                 "note": "beam-8 decode of 1920 crops (T_enc 13, 194 tokens) incl. the hoisted context GEMM, all 25 steps, no early exit; "
                         "ms_at_bench_run_length = the same launch inside the pipeline, where a chunk stops at its run length"}
+            # mode="greedy" (model.py:227-259) next to it: the round-1 VALU kernel, one workgroup per row — timed so the mode has a
+            # number at all; a matrix-core row-block form like the beam kernel's is not built
+            try:
+                rec.model.greedy(bH_, pH_, TRBA_CFG["max_len"], rec.sos_id, rec.eos_id, rec.blank_id)
+                torch.cuda.synchronize()
+                e0_.record()
+                for _ in range(3):
+                    rec.model.greedy(bH_, pH_, TRBA_CFG["max_len"], rec.sos_id, rec.eos_id, rec.blank_id)
+                e1_.record()
+                torch.cuda.synchronize()
+                ms_g = e0_.elapsed_time(e1_) / 3
+                res["roofline"]["decode_greedy_all_steps"] = {"crops": nb_, "steps": TRBA_CFG["max_len"] + 1, "ms": ms_g,
+                                                               "crops_per_s": nb_ / (ms_g * 1e-3), "kernel": "attn_greedy_kernel (VALU)"}
+            except Exception as e_g:
+                res["roofline"]["decode_greedy_all_steps"] = {"error": repr(e_g)[:200]}
         if os.environ.get("MSOCR_DUMP_CONV"):
             agg = {}
             for s_, e_, w, tag in gemm:
