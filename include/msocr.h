@@ -276,6 +276,13 @@ int msocr_attn_beam_hoisted(const float* batch_H, const float* proj_H, const flo
                             const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int beam, const float* lp_dev,
                             float temperature, int sos_id, int eos_id, int blank_id, int32_t* fin_step_out, void* workspace,
                             const int32_t* chunk_id_dev, const int32_t* chunk_size_dev, int32_t* chunk_state_dev, void* stream);
+/* msocr_attn_greedy on the matrix cores (round 4; Attention._greedy_decode, model.py:227-259): 32 crops per workgroup = one MFMA
+ * row block, the three per-step products in the split-operand form (ws must be given), the context half of the gate product
+ * hoisted as in msocr_attn_beam_hoisted.  Same outputs and argument meaning as msocr_attn_greedy; H == 256, V <= 256, T <= 48
+ * (other shapes: MSOCR_E_ARG — call msocr_attn_greedy). */
+int msocr_attn_greedy_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                              const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int sos_id, int eos_id,
+                              int blank_id, float* logits_out, int32_t* ids_out, void* stream);
 /* Packing of a decoder weight for the fields of msocr_attn_split_weights; HOST memory in and out.  wt: [256][N] f32 row-major (h2h_wt,
  * gen_wt) or, with gate_interleaved != 0, [256][N/4][4] (whh_t).  out: msocr_attn_pack_split_elems(N) = 3 * 256 * ceil32(N)
  * uint16 (bf16 bit patterns), laid out [plane][k / 16][column][k % 16] with wt == plane0 + plane1 + plane2 exactly. */

@@ -83,6 +83,8 @@ _SIGS = {
     "msocr_bilstm_recurrent_split": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "msocr_attn_greedy": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_vp, c_vp, c_vp]),
+    "msocr_attn_greedy_hoisted": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(AttnWeights), ctypes.POINTER(AttnSplitWeights), c_i32, c_i32,
+                                          c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "msocr_attn_beam": (c_i32, [c_vp, c_vp, ctypes.POINTER(AttnWeights), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32,
                                 c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_attn_pack_split_elems": (c_i64, [c_i32]),

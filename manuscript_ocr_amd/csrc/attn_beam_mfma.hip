@@ -676,6 +676,177 @@ __global__ __launch_bounds__(NT, 1) void attn_beam_mfma_kernel(AttnArgs a) {
   if (tid < NB && b0 + tid < a.B) a.fin_step[b0 + tid] = s_fin[tid];
 }
 
+// ------------------------------------------------------------------------------------------------- greedy (round 4)
+// mode="greedy" (Attention._greedy_decode, model.py:227-259) in the same row-block form: one 512-thread workgroup = 32 CROPS = 32
+// state rows = one MFMA row block, all `steps` steps in one launch.  The rows are independent (the reference keeps every row
+// running after its own EOS and only stops a chunk when all rows emit EOS in the same step; the host derives those run lengths
+// from the ids, recognizers/_trba/__init__.py), so a step is the beam kernel's (a)-(f) without any beam bookkeeping — no
+// log-softmax, no top-k, no state permutation — followed by an arg-max per row (larger value, then smaller index; blank masked
+// to -1e4 as in attn_greedy_kernel).  Split-operand products, hoisted context gates (a.ctx_gates), hardware-rate gate
+// nonlinearities: the arithmetic of attn_beam_mfma_kernel<true, true>.  Each row reads ITS crop's proj_H / ctx_gates frames
+// (8x the beam kernel's traffic per row, from L2 / the Infinity Cache).
+__global__ __launch_bounds__(NT, 1) void attn_greedy_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned char* sP = reinterpret_cast<unsigned char*>(lds);  // [3][R][PSB] bf16 planes of h
+  float* sbuf = lds + 3 * PPL / 4;                             // [R][H]    ph, then logits
+  float* salpha = sbuf + R * H;                                // [R][64]
+  __shared__ int s_tok[R];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int T = a.T, V = a.V;
+  const int b0 = blockIdx.x * R;
+  const int ju = 32 * wv + r32;
+  for (int i = tid; i < 3 * PPL / 4; i += NT) lds[i] = 0.f;   // h = 0
+  f32x16 c;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  if (tid < R) s_tok[tid] = a.sos_id;
+  __syncthreads();
+
+  for (int s = 0; s < a.steps; ++s) {
+    // ---- (a) ph[r][j] = h2h_b[j] + sum_k h[r][k] * h2h_wt[k][j]
+    {
+      f32x16 acc;
+      const float bj = a.w.h2h_b[ju];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = bj;
+      mfma_cols32_split(sP, a.h2h_p, H, ju, true, r32, half, acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sbuf[acc_row(e, half) * H + ju] = acc[e];
+    }
+    __syncthreads();
+    // ---- (b) e[r][t] = sum_j score_w[j] * tanh(proj_H[crop r][t][j] + ph[r][j]): one wave per (row, t), GB rows of proj_H in flight
+    {
+      constexpr int GB = 4;
+      float sw[H / 64];
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) sw[q] = a.w.score_w[lane + 64 * q];
+      const int ngroups = R * T;
+      for (int g0 = wv; g0 < ngroups; g0 += GB * (NT / 64)) {
+        float pr[GB][H / 64];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int g = g0 + u * (NT / 64);
+          if (g < ngroups) {
+            const int r = g / T, t = g - r * T;
+            const float* pP = a.proj_H + ((long)min(b0 + r, a.B - 1) * T + t) * H;
+#pragma unroll
+            for (int q = 0; q < H / 64; ++q) pr[u][q] = pP[lane + 64 * q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int g = g0 + u * (NT / 64);
+          if (g < ngroups) {
+            const int r = g / T, t = g - r * T;
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < H / 64; ++q) sacc = fmaf(sw[q], ftanh(pr[u][q] + sbuf[r * H + lane + 64 * q]), sacc);
+            sacc = wave_sum63(sacc);
+            if (lane == 63) salpha[r * 64 + t] = sacc;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (c) softmax over t: wave w handles rows 4w..4w+3, lane = t (T <= 64)
+    for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
+      const float ev0 = lane < T ? salpha[r * 64 + lane] : -INFINITY;
+      const float m = bcast63(wave_max63(ev0));
+      const float ev = lane < T ? expf(ev0 - m) : 0.f;
+      const float sum = bcast63(wave_sum63(ev));
+      if (lane < T) salpha[r * 64 + lane] = ev / sum;
+    }
+    __syncthreads();
+    // ---- (e) gates = b + W_ih_tok[token] + sum_t alpha_t P[crop][t] + W_hh h ; LSTM cell for units ju, rows acc_row(e, half)
+    {
+      f32x16 acc[4];
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&a.w.b_gates[ju * 4]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = acc_row(e, half);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&a.w.wih_tok[((long)s_tok[row] * H + ju) * 4]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g][e] = add_np(b4[g], t4[g]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {  // one row's frames (T x 16 B per lane, 8 in flight), then its FMAs; rows do not overlap
+        const float* pP = a.ctx_gates + ((long)min(b0 + acc_row(e, half), a.B - 1) * T * H + ju) * 4;
+        const float* pa = salpha + acc_row(e, half) * 64;
+        for (int t0 = 0; t0 < T; t0 += 8) {
+          f32x4 pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (t0 + u < T) pv[u] = *reinterpret_cast<const f32x4*>(pP + (long)(t0 + u) * H * 4);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (t0 + u < T) {
+              const float al = pa[t0 + u];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g][e] = fmac_np(al, pv[u][g], acc[g][e]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the rows' loads from piling up across iterations (registers)
+      }
+      mfma_gates_split(sP, a.whh_p, ju, r32, half, acc);
+      __syncthreads();  // every wave has read the old h
+      float hv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float ig = sigmoidf_(acc[0][e]), fg = sigmoidf_(acc[1][e]), gg = ftanh(acc[2][e]), og = sigmoidf_(acc[3][e]);
+        c[e] = fg * c[e] + ig * gg;
+        hv[e] = og * ftanh(c[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {  // acc_row(e + 1) == acc_row(e) + 1
+        unsigned char* d = sP + acc_row(e, half) * PSB + ju * 2;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint32_t pk = split_pair(hv[e], hv[e + 1]);
+          *reinterpret_cast<uint16_t*>(d + pl * PPL) = (uint16_t)pk;
+          *reinterpret_cast<uint16_t*>(d + pl * PPL + PSB) = (uint16_t)(pk >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (f) logits[r][v] = gen_b[v] + sum_k h'[r][k] * gen_wt[k][v]
+    {
+      const bool vok = ju < V;
+      f32x16 acc;
+      const float bv = vok ? a.w.gen_b[ju] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = bv;
+      if (32 * wv < V) mfma_cols32_split(sP, a.gen_p, (V + 31) & ~31, ju, true, r32, half, acc);  // padded columns are zeros
+      if (vok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = acc_row(e, half);
+          const float v = (ju == a.blank_id) ? -1e4f : acc[e];
+          sbuf[r * H + ju] = v;
+          if (b0 + r < a.B) a.logits_out[((long)(b0 + r) * a.steps + s) * V + ju] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (g) arg-max per row (larger value, then smaller index): wave w handles rows 4w..4w+3
+    for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int v = lane; v < V; v += 64) {
+        const float x = sbuf[r * H + v];
+        if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+      }
+      wave_argmax63(bv, bi);
+      if (lane == 63) {
+        if (bi == 0x7fffffff) bi = 0;  // every logit NaN: degenerate input
+        s_tok[r] = bi;
+        if (b0 + r < a.B) a.ids_out[(long)(b0 + r) * a.steps + s] = bi;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s) {
@@ -696,6 +867,19 @@ int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s) {
     MSOCR_LAUNCH((attn_beam_mfma_kernel<true, false>), grid, dim3(NT), ldsz, s, a);
   else
     MSOCR_LAUNCH((attn_beam_mfma_kernel<false, false>), grid, dim3(NT), ldsz, s, a);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+int msocr_internal_attn_greedy_mfma(const AttnArgs& a, hipStream_t s) {
+  if (!a.ctx_gates || !a.h2h_p || !a.whh_p || !a.gen_p) return MSOCR_E_ARG;
+  const size_t ldsz_split = (size_t)3 * PPL + (size_t)(R * H + R * 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_greedy_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz_split) != hipSuccess)
+      return MSOCR_E_LAUNCH;
+    attr = true;
+  }
+  MSOCR_LAUNCH(attn_greedy_mfma_kernel, dim3((a.B + R - 1) / R), dim3(NT), ldsz_split, s, a);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 

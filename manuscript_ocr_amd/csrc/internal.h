@@ -37,6 +37,8 @@ struct AttnArgs {
 };
 // attn_beam_mfma.hip: beam decode with 4 crops x 8 beams per workgroup on the f32 matrix cores (H == 256, beam <= 8, T <= 64)
 __attribute__((visibility("hidden"))) int msocr_internal_attn_beam_mfma(const AttnArgs& a, hipStream_t s);
+// attn_beam_mfma.hip: greedy decode with 32 crops per workgroup on the matrix cores (needs ctx_gates and the split weights)
+__attribute__((visibility("hidden"))) int msocr_internal_attn_greedy_mfma(const AttnArgs& a, hipStream_t s);
 // attn_general.hip: greedy / beam decode for hidden sizes other than 256, charsets above 256 tokens, beams above 8 (see its header
 // for the shapes taken); same outputs and workspace layout as the fast kernels.
 __attribute__((visibility("hidden"))) int msocr_internal_attn_general(const AttnArgs& a, int H, bool beam, hipStream_t s);

@@ -745,6 +745,26 @@ extern "C" int msocr_attn_greedy(const float* batch_H, const float* proj_H, cons
   return LAUNCH_OK();
 }
 
+// mode="greedy" on the matrix cores (attn_greedy_mfma_kernel, csrc/attn_beam_mfma.hip): 32 crops per workgroup, the three per-step
+// products in the split-operand form, the context half of the gate product hoisted (ctx_gates = batch_H x W_ih[:, :H]^T, [B][T][H][4],
+// computed once per call by a GEMM).  Same outputs as msocr_attn_greedy; hidden 256, V <= 256, T <= 48 only.
+extern "C" int msocr_attn_greedy_hoisted(const float* batch_H, const float* proj_H, const float* ctx_gates, const msocr_attn_weights* w,
+                                         const msocr_attn_split_weights* ws, int B, int T, int H, int V, int steps, int sos_id, int eos_id,
+                                         int blank_id, float* logits_out, int32_t* ids_out, void* stream) {
+  if (check_attn(batch_H, proj_H, w, B, T, H, V, steps) || !logits_out || !ids_out) return MSOCR_E_ARG;
+  if (sos_id < 0 || sos_id >= V || !attn_fast_shape(T, H, V)) return MSOCR_E_ARG;
+  if (!ctx_gates || ((uintptr_t)ctx_gates & 15)) return MSOCR_E_ARG;
+  if (!ws || !ws->h2h_p || !ws->whh_p || !ws->gen_p || (((uintptr_t)ws->h2h_p | (uintptr_t)ws->whh_p | (uintptr_t)ws->gen_p) & 15))
+    return MSOCR_E_ARG;
+  AttnArgs a{};
+  a.batch_H = batch_H; a.proj_H = proj_H; a.w = *w; a.ctx_gates = ctx_gates;
+  a.h2h_p = ws->h2h_p; a.whh_p = ws->whh_p; a.gen_p = ws->gen_p;
+  a.B = B; a.T = T; a.V = V; a.steps = steps; a.K = 1;
+  a.sos_id = sos_id; a.eos_id = eos_id; a.blank_id = blank_id; a.temperature = 1.0f;
+  a.logits_out = logits_out; a.ids_out = ids_out;
+  return msocr_internal_attn_greedy_mfma(a, (hipStream_t)stream);
+}
+
 // workspace: logits [B][steps][K][V] f32 | back [B][steps][K] i32 | tokv [B][steps][K] i32 | best_at [B][steps] i32
 static inline int64_t beam_ws_logits(int B, int steps, int K, int V) { return (int64_t)B * steps * K * V * 4; }
 extern "C" int64_t msocr_attn_beam_workspace_bytes(int B, int steps, int beam, int V) {

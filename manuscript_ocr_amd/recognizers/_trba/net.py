@@ -195,9 +195,18 @@ class TrbaNet:
         steps = max_len + 1
         logits = torch.empty((B, steps, self.V), dtype=torch.float32, device=self.device)
         ids = torch.empty((B, steps), dtype=torch.int32, device=self.device)
-        nat.check(nat.lib().msocr_attn_greedy(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
-                                              sos_id, eos_id, -1 if blank_id is None else blank_id, logits.data_ptr(), ids.data_ptr(),
-                                              ops._stream()), "attn_greedy")
+        blank = -1 if blank_id is None else blank_id
+        # default: the matrix-core row-block kernel (32 crops per workgroup, split-operand products, hoisted context gates), like
+        # the beam path; MSOCR_GREEDY_MFMA=0, precision="fp32-exact" and shapes outside the fast kernels: the VALU / general kernel
+        fast = H == 256 and self.V <= 256 and T <= 48 and getattr(self, "_asw", None) is not None
+        if fast and HOIST_CTX and os.environ.get("MSOCR_GREEDY_MFMA", "1") != "0":
+            ctxg = self._gemm(batch_H.reshape(B * T, H), self.att["wih_ctx_rows"], None)
+            nat.check(nat.lib().msocr_attn_greedy_hoisted(batch_H.data_ptr(), proj_H.data_ptr(), ctxg.data_ptr(), ctypes.byref(self._aw),
+                                                          ctypes.byref(self._asw), B, T, H, self.V, steps, sos_id, eos_id, blank,
+                                                          logits.data_ptr(), ids.data_ptr(), ops._stream()), "attn_greedy_hoisted")
+        else:
+            nat.check(nat.lib().msocr_attn_greedy(batch_H.data_ptr(), proj_H.data_ptr(), ctypes.byref(self._aw), B, T, H, self.V, steps,
+                                                  sos_id, eos_id, blank, logits.data_ptr(), ids.data_ptr(), ops._stream()), "attn_greedy")
         return logits, ids
 
     def beam(self, batch_H, proj_H, max_len, beam_size, alpha, temperature, sos_id, eos_id, blank_id, chunks=None):

@@ -181,6 +181,31 @@ def test_conv1x1_split_vs_exact_and_f64(ops, case, monkeypatch):
     assert torch.all(big[..., :32] == 7.0)
 
 
+@pytest.mark.parametrize("use_res", [False, True])
+def test_conv1x1_split_operand_above_4_gb_is_cut_into_row_ranges(ops, use_res):
+    """the lean loaders address rows with a 32-bit byte offset from a uniform base.  A 1x1 launch whose input spans
+    4 GB or more (here 4.4 M pixels x 256 channels f32 = 4.5 GB) is cut into row ranges on the host (bases advance in 64 bits,
+    csrc/conv_split.hip::launch_split_any) instead of wrapping its offsets: rows sampled from the first, the middle and the LAST
+    range — beyond 2^32 bytes — against an f64 product, through both kernels (no residual: conv_split_pp_kernel; with: conv_split_kernel)."""
+    M, Cin, Cout = 4_400_000, 256, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(1, M, 1, Cin, device="cuda", generator=g)
+    assert x.numel() * 4 > 2 ** 32
+    w = ops.attach_split((torch.randn(Cout, 1, 1, Cin, device="cuda", generator=g) * (2.0 / Cin) ** 0.5), True)
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    res = torch.randn(1, M, 1, Cout, device="cuda", generator=g) if use_res else None
+    out = ops.conv2d(x, w, b, relu=True, residual=res)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(M // 2 - 32, M // 2 + 32), torch.arange(M - 300, M)]).cuda()
+    ref = x[0, rows, 0].double() @ w.view(Cout, Cin).double().t() + b.double()
+    if use_res:
+        ref = ref + res[0, rows, 0].double()
+    ref = torch.relu(ref)
+    err = (out[0, rows, 0].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err
+    del x, out, res
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", [(3, 4, 13, 512, 512, False, False), (2, 8, 25, 256, 256, True, True), (1, 17, 9, 128, 192, True, False),
                                   (2, 12, 16, 160, 64, False, True)])
 def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):

@@ -375,6 +375,36 @@ def test_trba_bf16_cnn_close(env):
     assert err < 0.15 * max(1.0, np.abs(ref).max()), err
 
 
+def test_greedy_matrix_core_kernel_matches_the_valu_kernel_and_the_oracle(env, monkeypatch):
+    """mode="greedy" on the matrix cores (attn_greedy_mfma_kernel, 32 crops per workgroup, the default since round 4) against the
+    round-1 VALU kernel (MSOCR_GREEDY_MFMA=0) and against the oracle's greedy decode of the DEVICE's encoder output: 70 crops (two
+    full row blocks + a partial one), planted decoder — ids identical at every one of the 26 steps (the rows run on after their EOS,
+    as model.py:254 does), logits within 1e-3 of the largest logit."""
+    from manuscript_ocr_amd import synth
+    from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
+    otm = env
+    sd = synth.trba_state_dict_confident(194, 256, seed=11)
+    net = TrbaNet(sd, 194, 256, torch.float32)
+    B, max_len = 70, 25
+    cd = torch.from_numpy(synth.synth_crops(21, B, 32, 100)).cuda()
+    batch_H, proj_H = net.encode(cd)
+    lg_m, ids_m = net.greedy(batch_H, proj_H, max_len, 1, 2, None)
+    monkeypatch.setenv("MSOCR_GREEDY_MFMA", "0")
+    lg_v, ids_v = net.greedy(batch_H, proj_H, max_len, 1, 2, None)
+    monkeypatch.delenv("MSOCR_GREEDY_MFMA")
+    lg_m, ids_m, lg_v, ids_v = lg_m.cpu().numpy(), ids_m.cpu().numpy(), lg_v.cpu().numpy(), ids_v.cpu().numpy()
+    assert ids_m.shape == (B, max_len + 1) and np.array_equal(ids_m, ids_v)
+    assert np.abs(lg_m - lg_v).max() < 1e-3 * np.abs(lg_v).max()
+    ref_net = otm.TRBANet(194, 256)
+    ref_net.load_state_dict(sd, strict=True)
+    ref_net.eval()
+    with torch.no_grad():
+        rl, ri = ref_net.attn.greedy(batch_H.cpu(), max_len=max_len)
+    t_run = ri.shape[1]  # the oracle stops where the reference does; the device ran all steps
+    assert np.array_equal(ids_m[:, :t_run], ri.numpy())
+    assert np.abs(lg_m[:, :t_run] - rl.numpy()).max() < 1e-3 * np.abs(rl.numpy()).max()
+
+
 def test_beam_kernels_agree_and_early_exit_changes_nothing(env, monkeypatch):
     """Matrix-core beam kernel (default) vs the VALU kernel (MSOCR_BEAM_MFMA=0): same ids / finish steps, logits within 1e-3 of
     the largest logit; and the chunk-level early exit (rows grouped like the reference's batch_size chunks) leaves every
