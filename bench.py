@@ -419,6 +419,9 @@ def main():
             "words_per_page": len(words) / NP,
             "crops_per_page": n_crops / NP,
             "weights": "seeded synthetic (no checkpoint offline)",
+            "parity_shown_on": ("seeded synthetic weights only: no trained checkpoint exists offline.  Text identity with the CPU path is shown "
+                                "for the planted decoder (synth.trba_state_dict_confident, this workload) and, under the near-tie rule of "
+                                "DESIGN.md section 5, for the all-random decoder; maps / boxes / order against the oracle on the same weights"),
             "trba_decode": (None if rec is None or not getattr(rec, "last_rows", 0) else
                             {"max_len": TRBA_CFG["max_len"], "mean_chunk_run_length": round(rec.last_run_length_sum / rec.last_rows, 2),
                              "note": "the beam kernel leaves the step loop at each 32-crop chunk's run length, like the reference "
@@ -651,8 +654,8 @@ def main():
                 "ms_at_bench_run_length": att["avg_launch_ms"] if att else None,
                 "note": "beam-8 decode of 1920 crops (T_enc 13, 194 tokens) incl. the hoisted context GEMM, all 25 steps, no early exit; "
                         "ms_at_bench_run_length = the same launch inside the pipeline, where a chunk stops at its run length"}
-            # mode="greedy" (model.py:227-259) next to it: the round-1 VALU kernel, one workgroup per row — timed so the mode has a
-            # number at all; a matrix-core row-block form like the beam kernel's is not built
+            # mode="greedy" (model.py:227-259) next to it: attn_greedy_mfma_kernel (round 4: 32 crops per workgroup on the matrix
+            # cores; MSOCR_GREEDY_MFMA=0 = the round-1 VALU kernel, 4.6 against 3.0 ms for this launch)
             try:
                 rec.model.greedy(bH_, pH_, TRBA_CFG["max_len"], rec.sos_id, rec.eos_id, rec.blank_id)
                 torch.cuda.synchronize()
@@ -663,7 +666,7 @@ def main():
                 torch.cuda.synchronize()
                 ms_g = e0_.elapsed_time(e1_) / 3
                 res["roofline"]["decode_greedy_all_steps"] = {"crops": nb_, "steps": TRBA_CFG["max_len"] + 1, "ms": ms_g,
-                                                               "crops_per_s": nb_ / (ms_g * 1e-3), "kernel": "attn_greedy_kernel (VALU)"}
+                                                               "crops_per_s": nb_ / (ms_g * 1e-3), "kernel": "attn_greedy_mfma_kernel"}
             except Exception as e_g:
                 res["roofline"]["decode_greedy_all_steps"] = {"error": repr(e_g)[:200]}
         if os.environ.get("MSOCR_DUMP_CONV"):
