@@ -6,8 +6,12 @@
 // one interleaved scan, restart markers.  Anything else (progressive, arithmetic, CMYK, 12-bit, multi-scan, h1v2) is reported
 // as unsupported and the caller falls back to the host decoder.
 //
-// Split: the entropy-coded segment is a serial bit stream, so parsing + Huffman decoding run on the HOST
-// (msocr_jpeg_parse_host / msocr_jpeg_entropy_decode_host -> quantised DCT coefficients, 2 bytes each); everything per-pixel —
+// Split: the entropy-coded segment of a stream WITHOUT restart markers is one serial bit stream, so parsing + Huffman decoding run
+// on the HOST (msocr_jpeg_parse_host / msocr_jpeg_entropy_decode_host -> quantised DCT coefficients, 2 bytes each).  A stream WITH
+// a restart interval (DRI) is a sequence of independent, byte-aligned bit streams (DC predictors reset at every RSTn): the host only
+// walks the markers (msocr_jpeg_scan_prepare_host: interval bounds + Huffman tables), the file bytes go to the device as they are
+// and ONE THREAD PER INTERVAL decodes them there (msocr_jpeg_entropy_decode_device, round 4) — 0.3-0.6 MB of file bytes cross PCIe
+// instead of 9.4 MB of coefficients per 2048 x 1536 page, and no host core decodes anything.  Everything per-pixel —
 // dequantisation + inverse DCT, chroma upsampling, colour conversion — runs on the DEVICE (msocr_jpeg_reconstruct), so the
 // page's pixels are produced in HBM and never cross PCIe.  The reconstruction arithmetic is libjpeg's, restated from its
 // published algorithms (jidctint.c "islow" 13-bit fixed point, jdsample.c triangle-filter upsampling, jdcolor.c 16-bit YCC
@@ -342,6 +346,172 @@ int entropy_decode(const Parsed& P, const uint8_t* end, int16_t* coef) {
   return MSOCR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- entropy decode per interval
+// The decoder of ONE restart interval as a __host__ __device__ function: jpeg_huffman_kernel runs it one interval per thread,
+// msocr_jpeg_entropy_decode_intervals_host runs the same code interval after interval on the CPU (how the CPU suite pins it against
+// entropy_decode above and against PIL).  Same arithmetic and the same treatment of bad streams as entropy_decode: zeros are fed
+// past the end of the interval (= at its marker), an undecodable code / a coefficient index past 63 is an error for the whole page.
+struct DevTable {            // HuffTable without the construction state; 1420 bytes
+  uint16_t look[512];
+  int32_t maxcode[18];
+  int32_t valoff[17];
+  uint8_t vals[256];
+};
+struct ScanDesc {            // one page; msocr_jpeg_scan_desc_bytes() bytes, opaque to callers
+  msocr_jpeg_info info;
+  int64_t coef_base;         // int16 elements: the page's coefficient array inside the batch buffer
+  int64_t first_interval;    // index of the page's first (begin, end) pair
+  int32_t restart_interval, mcus_x, mcus_y, n_intervals;
+  DevTable dc[3], ac[3];     // per component (duplicates when components share a table)
+  uint8_t zigzag[64];
+};
+
+struct IntervalBits {
+  const uint8_t* base;
+  uint32_t pos, end;
+  uint64_t acc;
+  int nbits;
+  // at least 33 valid bits afterwards (a code of up to 16 bits + up to 15 value bits per symbol)
+  HD void refill() {
+    if (nbits > 32) return;
+    if (pos + 4 <= end) {
+      const uint32_t w = (uint32_t)base[pos] | ((uint32_t)base[pos + 1] << 8) | ((uint32_t)base[pos + 2] << 16) | ((uint32_t)base[pos + 3] << 24);
+      if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {  // no 0xFF among the four: no stuffing, no marker
+        const uint32_t be = (w << 24) | ((w & 0xff00u) << 8) | ((w >> 8) & 0xff00u) | (w >> 24);
+        acc = (acc << 32) | (uint64_t)be;
+        nbits += 32;
+        pos += 4;
+        return;
+      }
+    }
+    while (nbits <= 56) {
+      uint32_t b = 0;
+      if (pos < end) {
+        b = base[pos];
+        if (b == 0xFF) {
+          if (pos + 1 < end && base[pos + 1] == 0x00) pos += 2;   // stuffed byte
+          else { b = 0; end = pos; }                              // a marker: zeros from here on
+        } else {
+          ++pos;
+        }
+      }
+      acc = (acc << 8) | (uint64_t)b;
+      nbits += 8;
+    }
+  }
+  HD uint32_t peek(int n) const { return (uint32_t)(acc >> (nbits - n)) & ((1u << n) - 1u); }
+  HD void skip(int n) { nbits -= n; }
+};
+
+HD int interval_symbol(IntervalBits& br, const DevTable& t) {
+  const uint32_t look = br.peek(9);
+  const uint32_t e = t.look[look];
+  if (e) { br.skip((int)(e >> 8)); return (int)(e & 0xff); }
+  int l = 9;
+  int32_t code;
+  for (;;) {
+    ++l;
+    if (l > 16) return -1;
+    code = (int32_t)br.peek(l);
+    if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) break;
+  }
+  br.skip(l);
+  return t.vals[(code + t.valoff[l]) & 0xff];
+}
+
+// One Huffman symbol per loop iteration, the same instruction sequence for a DC difference and an AC run/size: the 64 lanes of a
+// wave decode 64 different intervals and stay converged except in the rare slow paths (codes longer than 9 bits, 0xFF bytes).
+// `coef` = the page's zero-filled coefficient array.  Returns 0, or 1 for a bad stream.
+HD int decode_interval(const msocr_jpeg_info& f, int mcus_x, const DevTable* dc, const DevTable* ac, const uint8_t* zigzag,
+                       const uint8_t* bytes, uint32_t begin, uint32_t end, int first_mcu, int n_mcu, int16_t* coef) {
+  IntervalBits br;
+  br.base = bytes; br.pos = begin; br.end = end; br.acc = 0; br.nbits = 0;
+  const int nb0 = f.hs[0] * f.vs[0];
+  const int per_mcu = f.ncomp == 3 ? nb0 + 2 : 1;
+  int pred0 = 0, pred1 = 0, pred2 = 0;
+  int mcu = first_mcu, b = 0, k = 0, c = 0;
+  int my = mcu / mcus_x, mx = mcu - my * mcus_x;
+  int64_t blk = f.coef_off[0] + ((int64_t)(my * f.vs[0]) * f.blocks_w[0] + mx * f.hs[0]) * 64;
+  const int last = first_mcu + n_mcu;
+  while (mcu < last) {
+    br.refill();
+    const int sym = interval_symbol(br, k == 0 ? dc[c] : ac[c]);
+    if (sym < 0) return 1;
+    const int sz = k == 0 ? sym : (sym & 15);
+    if (k == 0 && sz > 15) return 1;
+    int v = 0;
+    if (sz) {
+      v = (int)br.peek(sz);
+      br.skip(sz);
+      v = v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v;   // HUFF_EXTEND
+    }
+    if (k == 0) {
+      int pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+      pr = (int)((uint32_t)pr + (uint32_t)v);
+      if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+      coef[blk] = (int16_t)pr;
+      k = 1;
+    } else {
+      const int r = sym >> 4;
+      if (sz == 0) {
+        k = r == 15 ? k + 16 : 64;          // ZRL / EOB
+      } else {
+        k += r;
+        if (k > 63) return 1;
+        coef[blk + zigzag[k]] = (int16_t)v;
+        ++k;
+      }
+    }
+    if (k >= 64) {                          // next block of the MCU / next MCU
+      k = 0;
+      if (++b == per_mcu) {
+        b = 0;
+        ++mcu;
+        if (++mx == mcus_x) { mx = 0; ++my; }
+      }
+      c = b < nb0 ? 0 : b - nb0 + 1;
+      if (f.ncomp == 1) c = 0;
+      const int bi = c == 0 ? b : 0;
+      const int by = c == 0 ? bi / f.hs[0] : 0, bx = c == 0 ? bi - by * f.hs[0] : 0;
+      blk = f.coef_off[c] + ((int64_t)(my * f.vs[c] + by) * f.blocks_w[c] + (mx * f.hs[c] + bx)) * 64;
+    }
+  }
+  return 0;
+}
+
+void to_dev_table(const HuffTable& t, DevTable* o) {
+  memcpy(o->look, t.look, sizeof(o->look));
+  memcpy(o->maxcode, t.maxcode, sizeof(o->maxcode));
+  memcpy(o->valoff, t.valoff, sizeof(o->valoff));
+  memcpy(o->vals, t.vals, sizeof(o->vals));
+}
+
+// 64 threads = 64 consecutive intervals of ONE page (blockIdx.y): the page's six tables sit in LDS.
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const uint8_t* __restrict__ bytes, const ScanDesc* __restrict__ descs,
+                                                          const uint32_t* __restrict__ bounds, int16_t* __restrict__ coef,
+                                                          int32_t* __restrict__ status) {
+  __shared__ DevTable s_dc[3], s_ac[3];
+  __shared__ uint8_t s_zz[64];
+  const ScanDesc& d = descs[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= d.n_intervals) return;       // uniform
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.dc);
+    uint32_t* d0 = reinterpret_cast<uint32_t*>(s_dc);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(s_ac);
+    constexpr int W = (int)(3 * sizeof(DevTable) / 4);
+    for (int i = threadIdx.x; i < W; i += 64) { d0[i] = src[i]; d1[i] = src[W + i]; }
+    s_zz[threadIdx.x] = d.zigzag[threadIdx.x];
+  }
+  __syncthreads();
+  const int iv = blockIdx.x * 64 + threadIdx.x;
+  if (iv >= d.n_intervals) return;
+  const uint32_t begin = bounds[2 * (d.first_interval + iv)], end = bounds[2 * (d.first_interval + iv) + 1];
+  const int total = d.mcus_x * d.mcus_y;
+  const int first = iv * d.restart_interval;
+  const int n = total - first < d.restart_interval ? total - first : d.restart_interval;
+  if (decode_interval(d.info, d.mcus_x, s_dc, s_ac, s_zz, bytes, begin, end, first, n, coef + d.coef_base)) status[blockIdx.y] = 1;
+}
+
 // ---------------------------------------------------------------------------------------------------- reconstruction
 // jidctint.c, jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2
 #define C_0_298631336 2446
@@ -537,6 +707,94 @@ extern "C" int msocr_jpeg_entropy_decode_host(const uint8_t* data_host, int64_t 
   if (P.info.width != info->width || P.info.height != info->height || P.info.ncomp != info->ncomp ||
       P.info.coef_total != info->coef_total) return MSOCR_E_ARG;  // `info` must be what parse returned for this stream
   return entropy_decode(P, data_host + len, coef_out_host);
+}
+
+extern "C" int64_t msocr_jpeg_scan_desc_bytes(void) { return (int64_t)sizeof(ScanDesc); }
+
+// Walks the entropy-coded segment exactly as entropy_decode's restart handling does: interval k ends at the first marker (0xFF not
+// followed by 0x00) at or after its start, interval k + 1 starts behind the first RSTn at or after that marker.
+extern "C" int64_t msocr_jpeg_scan_prepare_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int64_t bytes_base,
+                                                int64_t coef_base, int64_t first_interval, void* desc_out, uint32_t* bounds_out,
+                                                int64_t bounds_cap) {
+  if (!data_host || !info || !desc_out || !bounds_out || bytes_base < 0 || coef_base < 0 || first_interval < 0) return MSOCR_E_ARG;
+  Parsed P;
+  if (parse(data_host, len, &P) != MSOCR_OK) return MSOCR_E_ARG;
+  if (P.info.width != info->width || P.info.height != info->height || P.info.ncomp != info->ncomp ||
+      P.info.coef_total != info->coef_total) return MSOCR_E_ARG;
+  if (P.restart_interval <= 0) return MSOCR_E_ARG;                       // one serial bit stream: the host decodes it
+  if (bytes_base + len > 0xfffffff0LL) return MSOCR_E_ARG;               // interval bounds are 32-bit offsets into the batch buffer
+  const int64_t total = (int64_t)P.mcus_x * P.mcus_y;
+  const int64_t n_iv = (total + P.restart_interval - 1) / P.restart_interval;
+  if (n_iv > bounds_cap || n_iv > 0x7fffffff) return MSOCR_E_ARG;
+  ScanDesc* d = static_cast<ScanDesc*>(desc_out);
+  memset(d, 0, sizeof(*d));
+  d->info = P.info;
+  d->coef_base = coef_base;
+  d->first_interval = first_interval;
+  d->restart_interval = P.restart_interval;
+  d->mcus_x = P.mcus_x; d->mcus_y = P.mcus_y; d->n_intervals = (int32_t)n_iv;
+  for (int c = 0; c < P.info.ncomp; ++c) {
+    to_dev_table(P.dc[P.dc_sel[c]], &d->dc[c]);
+    to_dev_table(P.ac[P.ac_sel[c]], &d->ac[c]);
+  }
+  memcpy(d->zigzag, kZigzag, 64);
+  const uint8_t* const end = data_host + len;
+  const uint8_t* p = P.scan;
+  for (int64_t k = 0; k < n_iv; ++k) {
+    const uint8_t* e = p;
+    for (;;) {                                                           // first 0xFF that is not a stuffed byte
+      e = e < end ? static_cast<const uint8_t*>(memchr(e, 0xFF, (size_t)(end - e))) : nullptr;
+      if (!e) { e = end; break; }
+      if (e + 1 < end && e[1] == 0x00) { e += 2; continue; }
+      break;
+    }
+    bounds_out[2 * k] = (uint32_t)(bytes_base + (p - data_host));
+    bounds_out[2 * k + 1] = (uint32_t)(bytes_base + (e - data_host));
+    if (k + 1 < n_iv) {
+      const uint8_t* q = e;
+      while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+      if (q + 1 >= end) return MSOCR_E_ARG;
+      p = q + 2;
+    }
+  }
+  return n_iv;
+}
+
+extern "C" int msocr_jpeg_entropy_decode_device(const uint8_t* bytes_dev, const void* descs_dev, int32_t n_pages, int32_t max_intervals,
+                                                const uint32_t* bounds_dev, int16_t* coef_dev, int64_t coef_total, int32_t* status_dev,
+                                                void* stream) {
+  if (!bytes_dev || !descs_dev || !bounds_dev || !coef_dev || !status_dev || n_pages <= 0 || n_pages > 65535 || max_intervals <= 0 ||
+      coef_total <= 0 || ((uintptr_t)descs_dev & 7))
+    return MSOCR_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(coef_dev, 0, (size_t)coef_total * sizeof(int16_t), s) != hipSuccess) return MSOCR_E_LAUNCH;
+  if (hipMemsetAsync(status_dev, 0, (size_t)n_pages * sizeof(int32_t), s) != hipSuccess) return MSOCR_E_LAUNCH;
+  MSOCR_LAUNCH(jpeg_huffman_kernel, dim3((unsigned)((max_intervals + 63) / 64), (unsigned)n_pages), dim3(64), 0, s, bytes_dev,
+               static_cast<const ScanDesc*>(descs_dev), bounds_dev, coef_dev, status_dev);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+// HOST twin of jpeg_huffman_kernel: the same decode_interval, interval after interval (all pointers host memory).
+extern "C" int msocr_jpeg_entropy_decode_intervals_host(const uint8_t* bytes_host, const void* descs_host, int32_t n_pages,
+                                                        const uint32_t* bounds_host, int16_t* coef_host, int64_t coef_total,
+                                                        int32_t* status_host) {
+  if (!bytes_host || !descs_host || !bounds_host || !coef_host || !status_host || n_pages <= 0 || coef_total <= 0) return MSOCR_E_ARG;
+  memset(coef_host, 0, (size_t)coef_total * sizeof(int16_t));
+  const ScanDesc* descs = static_cast<const ScanDesc*>(descs_host);
+  for (int pg = 0; pg < n_pages; ++pg) {
+    const ScanDesc& d = descs[pg];
+    status_host[pg] = 0;
+    if (d.coef_base < 0 || d.coef_base + d.info.coef_total > coef_total) return MSOCR_E_ARG;
+    const int total = d.mcus_x * d.mcus_y;
+    for (int iv = 0; iv < d.n_intervals; ++iv) {
+      const int first = iv * d.restart_interval;
+      const int n = total - first < d.restart_interval ? total - first : d.restart_interval;
+      if (decode_interval(d.info, d.mcus_x, d.dc, d.ac, d.zigzag, bytes_host, bounds_host[2 * (d.first_interval + iv)],
+                          bounds_host[2 * (d.first_interval + iv) + 1], first, n, coef_host + d.coef_base))
+        status_host[pg] = 1;
+    }
+  }
+  return MSOCR_OK;
 }
 
 extern "C" int64_t msocr_jpeg_workspace_bytes(const msocr_jpeg_info* info) { return info_ok(info) ? planes_bytes(*info) : -1; }

@@ -19,7 +19,9 @@ static uint32_t rnd() {
   return (uint32_t)(rng_state >> 11);
 }
 
+static long intervals_runs = 0;
 static int run_one(const std::vector<uint8_t>& d, long* accepted) {
+  long* intervals = &intervals_runs;
   msocr_jpeg_info info;
   // copy into an exactly-sized heap block so that a read past the end is an ASan error
   uint8_t* buf = (uint8_t*)malloc(d.size() ? d.size() : 1);
@@ -27,7 +29,23 @@ static int run_one(const std::vector<uint8_t>& d, long* accepted) {
   const int rc = msocr_jpeg_parse_host(buf, (int64_t)d.size(), &info);
   if (rc == 0 && info.supported && info.coef_total > 0 && info.coef_total < (int64_t)1 << 24 && (int64_t)info.width * info.height < (1 << 22)) {
     std::vector<int16_t> coef((size_t)info.coef_total);
-    if (msocr_jpeg_entropy_decode_host(buf, (int64_t)d.size(), &info, coef.data()) == 0) {
+    const int serial_rc = msocr_jpeg_entropy_decode_host(buf, (int64_t)d.size(), &info, coef.data());
+    {
+      // the per-interval decoder (host twin of the device Huffman kernel): same verdict, same coefficients as the serial decoder
+      std::vector<uint64_t> desc((size_t)(msocr_jpeg_scan_desc_bytes() + 7) / 8);
+      const int64_t cap = info.coef_total / 64 + 1;
+      std::vector<uint32_t> bounds((size_t)(2 * cap));
+      const int64_t niv = msocr_jpeg_scan_prepare_host(buf, (int64_t)d.size(), &info, 0, 0, 0, desc.data(), bounds.data(), cap);
+      if (niv > 0) {
+        std::vector<int16_t> coef2((size_t)info.coef_total);
+        int32_t status = 0;
+        if (msocr_jpeg_entropy_decode_intervals_host(buf, desc.data(), 1, bounds.data(), coef2.data(), info.coef_total, &status) != 0) return 1;
+        if ((status != 0) != (serial_rc != 0)) { fprintf(stderr, "verdicts differ: intervals %d serial %d\n", status, serial_rc); return 1; }
+        if (serial_rc == 0 && memcmp(coef.data(), coef2.data(), coef.size() * 2) != 0) { fprintf(stderr, "coefficients differ\n"); return 1; }
+        ++*intervals;
+      }
+    }
+    if (serial_rc == 0) {
       std::vector<uint8_t> rgb((size_t)info.width * info.height * 3);
       if (msocr_jpeg_reconstruct_host(&info, coef.data(), rgb.data()) != 0) return 1;
       ++*accepted;
@@ -80,6 +98,6 @@ int main(int argc, char** argv) {
       ++tried;
     }
   }
-  printf("jpeg_fuzz: %ld streams, %ld decoded to the end\n", tried, accepted);
+  printf("jpeg_fuzz: %ld streams, %ld decoded to the end, %ld also through the per-interval decoder\n", tried, accepted, intervals_runs);
   return 0;
 }

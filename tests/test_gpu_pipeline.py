@@ -384,6 +384,74 @@ def test_predict_batch_device_order_equals_host_order(gpu):
     assert sum(len(p.blocks[0].words) for p in a) > 60 and any(w.text for p in a for w in p.blocks[0].words)
 
 
+def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
+    """Round 4, SURVEY.md 8f.2: files written with a restart interval are entropy-decoded ON THE DEVICE, one thread per interval
+    (msocr_jpeg_entropy_decode_device): coefficients bit-identical to the serial host decoder, pixels bit-identical to PIL — for a
+    BATCH of files of every subsampling, grayscale, awkward sizes, interval lengths from one MCU to several MCU rows, optimised
+    tables; files without a restart interval in the same batch take the host decoder; a corrupt stream gets the host decoder's
+    verdict (None -> read_image); a 2048 x 1536 page batch as the bench writes it."""
+    import io
+    from PIL import Image
+    from manuscript_ocr_amd import ingest, synth
+    rng = np.random.default_rng(3)
+    srcs = [synth.synth_page(9, 203, 317)[0], rng.integers(0, 256, size=(64, 80, 3), dtype=np.uint8), synth.synth_page(11, 1111, 1531)[0]]
+    files, datas = [], []
+    for i, arr in enumerate(srcs):
+        for sub in (0, 1, 2):
+            for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 5}, {"restart_marker_rows": 1}, {"restart_marker_rows": 2, "optimize": True}, {}):
+                b = io.BytesIO()
+                Image.fromarray(arr).save(b, format="JPEG", quality=88, subsampling=sub, **kw)
+                datas.append(b.getvalue())
+    b = io.BytesIO()
+    Image.fromarray(srcs[2]).convert("L").save(b, format="JPEG", quality=80, restart_marker_rows=1)
+    datas.append(b.getvalue())
+    for k, d in enumerate(datas):
+        (tmp_path / f"f{k}.jpg").write_bytes(d)
+        files.append(str(tmp_path / f"f{k}.jpg"))
+    # (a) the kernel against the serial host decoder, coefficient for coefficient
+    parsed = [ingest._read_and_parse(f) for f in files]
+    batch = ingest.ScanBatch(parsed)
+    assert batch.n_pages == len(datas) - 9 and batch.max_intervals > 64       # 9 files without a restart interval
+    coef, status = ingest.entropy_batch_device(batch)
+    coef, status = coef.cpu().numpy(), status.cpu().numpy()
+    assert not status.any()
+    for i, d in enumerate(datas):
+        k = batch.pages[i]
+        if k >= 0:
+            info, ref = ingest.jpeg_coefficients(d)
+            assert np.array_equal(coef[batch.infos[k][1]: batch.infos[k][1] + int(info.coef_total)], ref), i
+    # (b) the batch reader: device Huffman + reconstruction == PIL for every file, with and without restart intervals
+    got = ingest.read_images_device(files)
+    for d, g in zip(datas, got):
+        assert g is not None and np.array_equal(g.cpu().numpy(), np.array(Image.open(io.BytesIO(d)).convert("RGB")))
+    assert np.array_equal(ingest.decode_jpeg_device(datas[0]).cpu().numpy(), ingest.decode_jpeg_device(datas[0], device_entropy=False).cpu().numpy())
+    # (c) a corrupt interval: same verdict as the host decoder, the other pages of the batch are untouched
+    bad = bytearray(datas[2])
+    sos = bytes(bad).index(b"\xff\xda")
+    verdicts = set()
+    for trial in range(40):
+        t = bytearray(bad)
+        for _ in range(3):
+            t[int(rng.integers(sos + 14, len(t) - 2))] = int(rng.integers(0, 255))
+        (tmp_path / "bad.jpg").write_bytes(bytes(t))
+        r = ingest.read_images_device([files[0], str(tmp_path / "bad.jpg"), files[2]])
+        ref = ingest.decode_jpeg_host(bytes(t))
+        assert (r[1] is None) == (ref is None)
+        if ref is not None:
+            assert np.array_equal(r[1].cpu().numpy(), ref)
+        verdicts.add(ref is None)
+        assert np.array_equal(r[0].cpu().numpy(), got[0].cpu().numpy()) and np.array_equal(r[2].cpu().numpy(), got[2].cpu().numpy())
+    assert verdicts == {True, False}
+    # (d) bench-sized pages: 4 x 2048 x 1536, one interval per MCU row
+    pages = [synth.synth_page(70 + k, 2048, 1536)[0] for k in range(4)]
+    big = []
+    for k, pg in enumerate(pages):
+        Image.fromarray(pg).save(tmp_path / f"p{k}.jpg", format="JPEG", quality=90, restart_marker_rows=1)
+        big.append(str(tmp_path / f"p{k}.jpg"))
+    for f, g in zip(big, ingest.read_images_device(big)):
+        assert np.array_equal(g.cpu().numpy(), np.array(Image.open(f).convert("RGB")))
+
+
 def test_device_jpeg_ingest(gpu, tmp_path):
     """SURVEY.md 8f.2 image ingest: a JPEG page decoded on the device (host Huffman stage + HIP dequant / IDCT / upsample /
     colour kernels) is bit-identical to PIL's decode (what the reference's read_image returns), for 4:2:0 / 4:2:2 / 4:4:4 and
@@ -470,13 +538,15 @@ def test_ragged_page_batches_equal_per_page_calls(gpu):
     assert sum(w.text is not None for p in together for w in p.blocks[0].words) > 50
 
 
-@pytest.mark.parametrize("H,W,n_pages,rounds", [(512, 768, 2, 3), (1536, 2048, 4, 2)])
+@pytest.mark.parametrize("H,W,n_pages,rounds", [(512, 768, 2, 3), (1536, 2048, 4, 4)])
 def test_whole_pipeline_hipgraph_replay_equals_eager(gpu, H, W, n_pages, rounds):
     """BASELINE configs[3] "hipGraph-captured": EAST(use_graphs=True) + TRBA(use_graphs=True) — detector (resize, network, decode,
     LANMS, box filters) and recogniser (device crops, SE-ResNet31, BiLSTMs, beam decode) each replayed from a hipGraph — return
     the same Pages as plain launches, call after call (first call of a shape runs eagerly, the second captures, later ones replay),
     also when the number of crops changes between calls (row buckets of 32 with a padding chunk).  Second case: the captured
-    sequence at configs[3]'s real shapes — 4 pages @ 1536 x 2048, 1400-1900 crops per call (VERDICT r3 #8)."""
+    sequence at configs[3]'s real shapes — 4 pages @ 1536 x 2048, 1400-1900 crops per call; four rounds, because consecutive batches alternate between
+    two stream sets and a graph is keyed by its launch stream: every (stream set, page set) pair is seen twice — eager, then captured
+    and replayed."""
     from manuscript_ocr_amd import Pipeline, synth
     from manuscript_ocr_amd.detectors import EAST
     from manuscript_ocr_amd.recognizers import TRBA

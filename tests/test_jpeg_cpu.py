@@ -178,7 +178,8 @@ def test_jpeg_host_parser_under_sanitizers(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", san[0], str(obj), str(drv), "-o", str(exe)])
     arr = _test_images()["page"][:96, :128]
     seeds = []
-    for k, (q, sub, kw) in enumerate(((80, 2, {}), (90, 0, {"optimize": True}), (60, 1, {"restart_marker_blocks": 2}))):
+    for k, (q, sub, kw) in enumerate(((80, 2, {}), (90, 0, {"optimize": True}), (60, 1, {"restart_marker_blocks": 2}),
+                                   (85, 2, {"restart_marker_rows": 1}))):
         try:
             data = _encode(arr, quality=q, subsampling=sub, **kw)
         except TypeError:
@@ -189,4 +190,87 @@ def test_jpeg_host_parser_under_sanitizers(tmp_path):
                        env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "streams" in r.stdout
+    assert int(r.stdout.split("decoded to the end,")[1].split()[0]) > 100, r.stdout   # the per-interval decoder saw hostile streams too
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def _parsed(data):
+    info, buf = ingest._parse(data)
+    return None if info is None else (info, buf, len(data))
+
+
+def test_jpeg_per_interval_decoder_equals_the_serial_decoder_and_pil():
+    """Round 4: streams with a restart interval are decoded one interval per device thread (csrc/jpeg.hip decode_interval).  Its HOST
+    twin — the same __host__ __device__ function, interval after interval — must give the serial host decoder's coefficients bit
+    for bit, for a BATCH of streams of every subsampling, awkward sizes (partial MCUs, last interval shorter than the others) and
+    interval lengths from 1 MCU to several rows; streams without a restart interval are left to the host decoder."""
+    imgs = _test_images()
+    datas, expect = [], []
+    for name in ("page", "noise", "smooth", "tiny", "narrow"):
+        for sub in (0, 1, 2):
+            for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 7}, {"restart_marker_rows": 1}, {"restart_marker_rows": 3}, {}):
+                datas.append(_encode(imgs[name], quality=85, subsampling=sub, **kw))
+                expect.append(bool(kw))
+    datas.append(_encode(imgs["page"][:, :, 0], quality=70, restart_marker_rows=1))           # grayscale
+    expect.append(True)
+    datas.append(_encode(imgs["noise"], quality=100, subsampling=0, optimize=True, restart_marker_blocks=2))   # long codes, optimised tables
+    expect.append(True)
+    parsed = [_parsed(d) for d in datas]
+    batch = ingest.ScanBatch(parsed)
+    assert [k >= 0 for k in batch.pages] == expect
+    coef, status = ingest.entropy_batch_host_twin(batch)
+    assert not status.any()
+    for i, d in enumerate(datas):
+        k = batch.pages[i]
+        if k < 0:
+            continue
+        info, ref = ingest.jpeg_coefficients(d)
+        base = batch.infos[k][1]
+        assert np.array_equal(coef[base: base + int(info.coef_total)], ref), i
+    # ... and through the reconstruction twin against PIL, for one of them
+    k = batch.pages[2]
+    info, base = batch.infos[k]
+    import ctypes
+
+    from manuscript_ocr_amd import _native as nat
+    out = np.empty((info.height, info.width, 3), dtype=np.uint8)
+    page = np.ascontiguousarray(coef[base: base + int(info.coef_total)])
+    nat.check(nat.lib().msocr_jpeg_reconstruct_host(ctypes.byref(info), page.ctypes.data, out.ctypes.data), "reconstruct")
+    assert np.array_equal(out, _pil_decode(datas[2]))
+
+
+def test_jpeg_per_interval_decoder_bad_streams_get_the_host_decoders_verdict():
+    """Corrupt entropy data inside an interval, a missing RSTn, truncation: the per-interval decoder flags the page (status 1) or the
+    marker walk refuses it exactly when the serial decoder refuses the stream; when both accept, the coefficients are identical
+    (zeros are fed past an interval's end in both)."""
+    rng = np.random.default_rng(11)
+    base_data = _encode(_test_images()["page"], quality=80, subsampling=2, restart_marker_blocks=3)
+    sos = base_data.index(b"\xff\xda")
+    cases = [base_data]
+    for _ in range(60):
+        b = bytearray(base_data)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    cases.append(base_data[: sos + (len(base_data) - sos) // 2])                               # truncated in the scan
+    rst = base_data.index(b"\xff\xd0", sos)
+    cases.append(base_data[:rst] + base_data[rst + 2:])                                        # first RST marker removed
+    agree = refused = 0
+    for d in cases:
+        pr = _parsed(d)
+        if pr is None:
+            continue
+        ref = ingest.jpeg_coefficients(d)
+        batch = ingest.ScanBatch([pr])
+        if batch.n_pages == 0:
+            assert ref is None, "the marker walk refused a stream the serial decoder takes"
+            refused += 1
+            continue
+        coef, status = ingest.entropy_batch_host_twin(batch)
+        assert (status[0] != 0) == (ref is None)
+        if ref is not None:
+            assert np.array_equal(coef, ref[1])
+            agree += 1
+        else:
+            refused += 1
+    assert agree >= 10 and refused >= 1, (agree, refused)
