@@ -468,7 +468,7 @@ def main():
                     paths.append(os.path.join(td, f"p{i_}.jpg"))
                     _Image.fromarray(pg_).save(paths[-1], quality=90)
                     paths_dri.append(os.path.join(td, f"r{i_}.jpg"))
-                    _Image.fromarray(pg_).save(paths_dri[-1], quality=90, restart_marker_rows=1)
+                    _Image.fromarray(pg_).save(paths_dri[-1], quality=90, restart_marker_blocks=16)
                 pages, a.host_pages = paths_dri, True     # file bytes -> device Huffman stage (one thread per restart interval) -> device reconstruction
                 sec["jpeg_ingest"] = secondary_rate()
                 pages = paths                             # no restart markers: entropy decode on a host thread pool (ingest.py)
@@ -480,7 +480,7 @@ def main():
             pipe, pages, a.host_pages = keep
         sec["note"] = ("pages/s of the same loop, 3 steps each after the timed region: host_pages = pages handed over as host arrays "
                        "(PCIe-inclusive), graphs = EAST/TRBA(use_graphs=True), jpeg_ingest = pages read from JPEG files (quality 90, "
-                       "4:2:0, one restart interval per MCU row) through ingest.py: Huffman stage AND reconstruction on the device; "
+                       "4:2:0, restart interval 16 MCUs) through ingest.py: Huffman stage AND reconstruction on the device; "
                        "jpeg_ingest_host_entropy = the same pages written without restart markers: entropy decode on a host thread "
                        "pool, reconstruction on the device")
         res["secondary_lines"] = sec

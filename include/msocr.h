@@ -355,27 +355,27 @@ typedef struct msocr_jpeg_info {
 int msocr_jpeg_parse_host(const uint8_t* data_host, int64_t len, msocr_jpeg_info* info_out);
 int msocr_jpeg_entropy_decode_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int16_t* coef_out_host);
 /* Device-side entropy decode of a BATCH of streams with restart intervals (DRI): the intervals between RSTn markers are independent
- * byte-aligned bit streams.  Host, per page: msocr_jpeg_scan_prepare_host walks the markers of a stream msocr_jpeg_parse_host
- * accepted and writes (a) the page's descriptor — msocr_jpeg_scan_desc_bytes() opaque bytes: frame geometry, Huffman tables, where
- * the page's coefficients go (coef_base, int16 elements into the batch coefficient buffer) and where its interval bounds start
- * (first_interval) — and (b) one (begin, end) pair of uint32 byte offsets per interval into the batch byte buffer, in which this
- * file's first byte sits at bytes_base.  Returns the number of intervals, or MSOCR_E_ARG (no restart interval / corrupt marker
- * sequence / more than bounds_cap intervals / batch buffer beyond 4 GB: use msocr_jpeg_entropy_decode_host).
+ * byte-aligned bit streams.  Host, per page (thread-safe; no state): msocr_jpeg_scan_prepare_host walks the markers of a stream
+ * msocr_jpeg_parse_host accepted and writes (a) the page's descriptor — msocr_jpeg_scan_desc_bytes() opaque bytes: frame geometry,
+ * Huffman tables, bytes_base = where the file's first byte sits in the batch byte buffer — and (b) one (begin, end) pair of uint32
+ * byte offsets INTO THE FILE per interval.  Returns the number of intervals, or MSOCR_E_ARG (no restart interval / corrupt marker
+ * sequence / more than bounds_cap intervals: use msocr_jpeg_entropy_decode_host).
  * Device: msocr_jpeg_entropy_decode_device(bytes_dev = the files' bytes as they are on disk, descs_dev [n_pages] descriptors (8-byte
- * aligned), max_intervals = the largest interval count of a page, bounds_dev, coef_dev [coef_total] int16 (zero-filled by this
- * call), status_dev [n_pages]: 0, or 1 = the page's stream is bad (same verdict as msocr_jpeg_entropy_decode_host: take the host
- * reader)).  Bit-identical coefficients to msocr_jpeg_entropy_decode_host.  msocr_jpeg_entropy_decode_intervals_host is the HOST
- * twin of the kernel (same per-interval decoder; all pointers host memory). */
+ * aligned), max_intervals = the largest interval count of a page, bounds_dev = the pages' pairs one page after the other,
+ * page_base_dev [n_pages][2] int64 = {where the page's coefficient array starts in coef_dev (int16 elements), index of the page's
+ * first pair in bounds_dev}, coef_dev [coef_total] int16 (zero-filled by this call), status_dev [n_pages]: 0, or 1 = the page's
+ * stream is bad (same verdict as msocr_jpeg_entropy_decode_host: take the host reader)).  Bit-identical coefficients to
+ * msocr_jpeg_entropy_decode_host.  msocr_jpeg_entropy_decode_intervals_host is the HOST twin of the kernel (same per-interval
+ * decoder; all pointers host memory). */
 int64_t msocr_jpeg_scan_desc_bytes(void);
 int64_t msocr_jpeg_scan_prepare_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int64_t bytes_base,
-                                     int64_t coef_base, int64_t first_interval, void* desc_out, uint32_t* bounds_out,
-                                     int64_t bounds_cap);
+                                     void* desc_out, uint32_t* bounds_out, int64_t bounds_cap);
 int msocr_jpeg_entropy_decode_device(const uint8_t* bytes_dev, const void* descs_dev, int32_t n_pages, int32_t max_intervals,
-                                     const uint32_t* bounds_dev, int16_t* coef_dev, int64_t coef_total, int32_t* status_dev,
-                                     void* stream);
+                                     const uint32_t* bounds_dev, const int64_t* page_base_dev, int16_t* coef_dev, int64_t coef_total,
+                                     int32_t* status_dev, void* stream);
 int msocr_jpeg_entropy_decode_intervals_host(const uint8_t* bytes_host, const void* descs_host, int32_t n_pages,
-                                             const uint32_t* bounds_host, int16_t* coef_host, int64_t coef_total,
-                                             int32_t* status_host);
+                                             const uint32_t* bounds_host, const int64_t* page_base_host, int16_t* coef_host,
+                                             int64_t coef_total, int32_t* status_host);
 int64_t msocr_jpeg_workspace_bytes(const msocr_jpeg_info* info);
 int msocr_jpeg_reconstruct(const msocr_jpeg_info* info, const int16_t* coef_dev, void* workspace_dev, uint8_t* rgb_out_dev,
                            void* stream);

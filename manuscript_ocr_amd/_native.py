@@ -105,9 +105,9 @@ _SIGS = {
     "msocr_jpeg_parse_host": (c_i32, [c_vp, c_i64, ctypes.POINTER(JpegInfo)]),
     "msocr_jpeg_entropy_decode_host": (c_i32, [c_vp, c_i64, ctypes.POINTER(JpegInfo), c_vp]),
     "msocr_jpeg_scan_desc_bytes": (c_i64, []),
-    "msocr_jpeg_scan_prepare_host": (c_i64, [c_vp, c_i64, ctypes.POINTER(JpegInfo), c_i64, c_i64, c_i64, c_vp, c_vp, c_i64]),
-    "msocr_jpeg_entropy_decode_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "msocr_jpeg_entropy_decode_intervals_host": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "msocr_jpeg_scan_prepare_host": (c_i64, [c_vp, c_i64, ctypes.POINTER(JpegInfo), c_i64, c_vp, c_vp, c_i64]),
+    "msocr_jpeg_entropy_decode_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "msocr_jpeg_entropy_decode_intervals_host": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "msocr_jpeg_workspace_bytes": (c_i64, [ctypes.POINTER(JpegInfo)]),
     "msocr_jpeg_reconstruct": (c_i32, [ctypes.POINTER(JpegInfo), c_vp, c_vp, c_vp, c_vp]),
     "msocr_jpeg_reconstruct_host": (c_i32, [ctypes.POINTER(JpegInfo), c_vp, c_vp]),

@@ -363,7 +363,6 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
   };
 
   uint32_t so = 0;                                         // byte offset of the stage being read
-  int g = 0;
   // one K-tile = RS units (one streamed block x all held blocks, 6 RH MFMAs).  FIRST = the first K-tile of an output tile: unit s
   // first stores the previous tile's blocks of streamed index s (prev), then starts them anew.  PEND_FIRST = the K-tile BEFORE
   // this one was such a first K-tile (its last unit's partial sums are committed in this one's unit 0).
@@ -402,7 +401,6 @@ __global__ __launch_bounds__(512, 2) void conv_split_pp_kernel(ConvParams p, int
       read_held(h_c, so);
       __builtin_amdgcn_sched_barrier(0);
     });
-    ++g;
   };
 
   lds_barrier();                                           // #0

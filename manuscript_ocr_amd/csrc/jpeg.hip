@@ -19,6 +19,7 @@
 // test-suite pins it bit for bit against PIL's decode of the same files.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -359,8 +360,7 @@ struct DevTable {            // HuffTable without the construction state; 1420 b
 };
 struct ScanDesc {            // one page; msocr_jpeg_scan_desc_bytes() bytes, opaque to callers
   msocr_jpeg_info info;
-  int64_t coef_base;         // int16 elements: the page's coefficient array inside the batch buffer
-  int64_t first_interval;    // index of the page's first (begin, end) pair
+  int64_t bytes_base;        // where the file's first byte sits in the batch byte buffer (the interval bounds are relative to the FILE)
   int32_t restart_interval, mcus_x, mcus_y, n_intervals;
   DevTable dc[3], ac[3];     // per component (duplicates when components share a table)
   uint8_t zigzag[64];
@@ -374,15 +374,33 @@ struct IntervalBits {
   // at least 33 valid bits afterwards (a code of up to 16 bits + up to 15 value bits per symbol)
   HD void refill() {
     if (nbits > 32) return;
-    if (pos + 4 <= end) {
-      const uint32_t w = (uint32_t)base[pos] | ((uint32_t)base[pos + 1] << 8) | ((uint32_t)base[pos + 2] << 16) | ((uint32_t)base[pos + 3] << 24);
-      if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {  // no 0xFF among the four: no stuffing, no marker
-        const uint32_t be = (w << 24) | ((w & 0xff00u) << 8) | ((w >> 8) & 0xff00u) | (w >> 24);
+    if (pos + 5 <= end) {
+      // four stream bytes + one of lookahead, un-stuffed in registers: a lane that meets a 0xFF takes no memory round trips, so a
+      // wave whose lanes are at different places of different streams pays the same few ALU instructions either way
+      const uint64_t w = (uint64_t)base[pos] | ((uint64_t)base[pos + 1] << 8) | ((uint64_t)base[pos + 2] << 16) |
+                         ((uint64_t)base[pos + 3] << 24) | ((uint64_t)base[pos + 4] << 32);
+      const uint32_t lo = (uint32_t)w;
+      if ((((~lo) - 0x01010101u) & lo & 0x80808080u) == 0) {  // no 0xFF among the four: no stuffing, no marker
+        const uint32_t be = (lo << 24) | ((lo & 0xff00u) << 8) | ((lo >> 8) & 0xff00u) | (lo >> 24);
         acc = (acc << 32) | (uint64_t)be;
         nbits += 32;
         pos += 4;
         return;
       }
+      uint32_t i = 0;
+      bool marker = false;
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        if (!marker && i < 4) {
+          const uint32_t b = (uint32_t)(w >> (8 * i)) & 0xff, n = (uint32_t)(w >> (8 * i + 8)) & 0xff;
+          if (b != 0xFF) { acc = (acc << 8) | b; nbits += 8; i += 1; }
+          else if (n == 0) { acc = (acc << 8) | 0xFF; nbits += 8; i += 2; }   // stuffed byte
+          else marker = true;                                                 // zeros from here on
+        }
+      }
+      pos += i;
+      if (marker) end = pos;
+      if (nbits > 32) return;
     }
     while (nbits <= 56) {
       uint32_t b = 0;
@@ -486,14 +504,18 @@ void to_dev_table(const HuffTable& t, DevTable* o) {
   memcpy(o->vals, t.vals, sizeof(o->vals));
 }
 
-// 64 threads = 64 consecutive intervals of ONE page (blockIdx.y): the page's six tables sit in LDS.
+// One wave = `lanes` consecutive intervals of ONE page (blockIdx.y); the page's six tables sit in LDS (all 64 threads load them).
+// lanes < 64 when the batch has fewer intervals than the chip has wave slots: the decoder is a chain of dependent instructions, a
+// lane costs the same whether its 63 neighbours work or not, and a wave executes the UNION of its lanes' slow paths (a 0xFF byte,
+// a code longer than 9 bits) — so few intervals are spread one per wave over the 1024 SIMDs instead of packed into 32 waves
+// (16 pages x 128 intervals: 22.7 ms packed).
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const uint8_t* __restrict__ bytes, const ScanDesc* __restrict__ descs,
-                                                          const uint32_t* __restrict__ bounds, int16_t* __restrict__ coef,
-                                                          int32_t* __restrict__ status) {
+                                                          const uint32_t* __restrict__ bounds, const int64_t* __restrict__ page_base,
+                                                          int16_t* __restrict__ coef, int32_t* __restrict__ status, int lanes) {
   __shared__ DevTable s_dc[3], s_ac[3];
   __shared__ uint8_t s_zz[64];
   const ScanDesc& d = descs[blockIdx.y];
-  if ((int)blockIdx.x * 64 >= d.n_intervals) return;       // uniform
+  if ((int)blockIdx.x * lanes >= d.n_intervals) return;    // uniform
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(d.dc);
     uint32_t* d0 = reinterpret_cast<uint32_t*>(s_dc);
@@ -503,13 +525,14 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const uint8_t* __restr
     s_zz[threadIdx.x] = d.zigzag[threadIdx.x];
   }
   __syncthreads();
-  const int iv = blockIdx.x * 64 + threadIdx.x;
-  if (iv >= d.n_intervals) return;
-  const uint32_t begin = bounds[2 * (d.first_interval + iv)], end = bounds[2 * (d.first_interval + iv) + 1];
+  const int iv = blockIdx.x * lanes + threadIdx.x;
+  if ((int)threadIdx.x >= lanes || iv >= d.n_intervals) return;
+  const int64_t coef_base = page_base[2 * blockIdx.y], first_interval = page_base[2 * blockIdx.y + 1];
+  const uint32_t begin = bounds[2 * (first_interval + iv)], end = bounds[2 * (first_interval + iv) + 1];
   const int total = d.mcus_x * d.mcus_y;
   const int first = iv * d.restart_interval;
   const int n = total - first < d.restart_interval ? total - first : d.restart_interval;
-  if (decode_interval(d.info, d.mcus_x, s_dc, s_ac, s_zz, bytes, begin, end, first, n, coef + d.coef_base)) status[blockIdx.y] = 1;
+  if (decode_interval(d.info, d.mcus_x, s_dc, s_ac, s_zz, bytes + d.bytes_base, begin, end, first, n, coef + coef_base)) status[blockIdx.y] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------- reconstruction
@@ -714,23 +737,21 @@ extern "C" int64_t msocr_jpeg_scan_desc_bytes(void) { return (int64_t)sizeof(Sca
 // Walks the entropy-coded segment exactly as entropy_decode's restart handling does: interval k ends at the first marker (0xFF not
 // followed by 0x00) at or after its start, interval k + 1 starts behind the first RSTn at or after that marker.
 extern "C" int64_t msocr_jpeg_scan_prepare_host(const uint8_t* data_host, int64_t len, const msocr_jpeg_info* info, int64_t bytes_base,
-                                                int64_t coef_base, int64_t first_interval, void* desc_out, uint32_t* bounds_out,
-                                                int64_t bounds_cap) {
-  if (!data_host || !info || !desc_out || !bounds_out || bytes_base < 0 || coef_base < 0 || first_interval < 0) return MSOCR_E_ARG;
+                                                void* desc_out, uint32_t* bounds_out, int64_t bounds_cap) {
+  if (!data_host || !info || !desc_out || !bounds_out || bytes_base < 0) return MSOCR_E_ARG;
   Parsed P;
   if (parse(data_host, len, &P) != MSOCR_OK) return MSOCR_E_ARG;
   if (P.info.width != info->width || P.info.height != info->height || P.info.ncomp != info->ncomp ||
       P.info.coef_total != info->coef_total) return MSOCR_E_ARG;
   if (P.restart_interval <= 0) return MSOCR_E_ARG;                       // one serial bit stream: the host decodes it
-  if (bytes_base + len > 0xfffffff0LL) return MSOCR_E_ARG;               // interval bounds are 32-bit offsets into the batch buffer
+  if (len > 0xfffffff0LL) return MSOCR_E_ARG;                            // interval bounds are 32-bit offsets into the file
   const int64_t total = (int64_t)P.mcus_x * P.mcus_y;
   const int64_t n_iv = (total + P.restart_interval - 1) / P.restart_interval;
   if (n_iv > bounds_cap || n_iv > 0x7fffffff) return MSOCR_E_ARG;
   ScanDesc* d = static_cast<ScanDesc*>(desc_out);
   memset(d, 0, sizeof(*d));
   d->info = P.info;
-  d->coef_base = coef_base;
-  d->first_interval = first_interval;
+  d->bytes_base = bytes_base;
   d->restart_interval = P.restart_interval;
   d->mcus_x = P.mcus_x; d->mcus_y = P.mcus_y; d->n_intervals = (int32_t)n_iv;
   for (int c = 0; c < P.info.ncomp; ++c) {
@@ -748,8 +769,8 @@ extern "C" int64_t msocr_jpeg_scan_prepare_host(const uint8_t* data_host, int64_
       if (e + 1 < end && e[1] == 0x00) { e += 2; continue; }
       break;
     }
-    bounds_out[2 * k] = (uint32_t)(bytes_base + (p - data_host));
-    bounds_out[2 * k + 1] = (uint32_t)(bytes_base + (e - data_host));
+    bounds_out[2 * k] = (uint32_t)(p - data_host);
+    bounds_out[2 * k + 1] = (uint32_t)(e - data_host);
     if (k + 1 < n_iv) {
       const uint8_t* q = e;
       while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
@@ -761,36 +782,52 @@ extern "C" int64_t msocr_jpeg_scan_prepare_host(const uint8_t* data_host, int64_
 }
 
 extern "C" int msocr_jpeg_entropy_decode_device(const uint8_t* bytes_dev, const void* descs_dev, int32_t n_pages, int32_t max_intervals,
-                                                const uint32_t* bounds_dev, int16_t* coef_dev, int64_t coef_total, int32_t* status_dev,
-                                                void* stream) {
-  if (!bytes_dev || !descs_dev || !bounds_dev || !coef_dev || !status_dev || n_pages <= 0 || n_pages > 65535 || max_intervals <= 0 ||
-      coef_total <= 0 || ((uintptr_t)descs_dev & 7))
+                                                const uint32_t* bounds_dev, const int64_t* page_base_dev, int16_t* coef_dev,
+                                                int64_t coef_total, int32_t* status_dev, void* stream) {
+  if (!bytes_dev || !descs_dev || !bounds_dev || !page_base_dev || !coef_dev || !status_dev || n_pages <= 0 || n_pages > 65535 ||
+      max_intervals <= 0 || coef_total <= 0 || (((uintptr_t)descs_dev | (uintptr_t)page_base_dev) & 7))
     return MSOCR_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(coef_dev, 0, (size_t)coef_total * sizeof(int16_t), s) != hipSuccess) return MSOCR_E_LAUNCH;
   if (hipMemsetAsync(status_dev, 0, (size_t)n_pages * sizeof(int32_t), s) != hipSuccess) return MSOCR_E_LAUNCH;
-  MSOCR_LAUNCH(jpeg_huffman_kernel, dim3((unsigned)((max_intervals + 63) / 64), (unsigned)n_pages), dim3(64), 0, s, bytes_dev,
-               static_cast<const ScanDesc*>(descs_dev), bounds_dev, coef_dev, status_dev);
+  // wave slots wanted: two per SIMD of the device; lanes per wave = the power of two that fills them
+  static int slots = 0;
+  static int lanes_env = -1;
+  if (!slots) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MSOCR_E_LAUNCH;
+    slots = prop.multiProcessorCount * 8;
+    const char* e = getenv("MSOCR_JPEG_LANES");
+    lanes_env = e ? atoi(e) : 0;
+  }
+  int lanes = 1;
+  while (lanes < 64 && (int64_t)n_pages * max_intervals > (int64_t)slots * lanes) lanes *= 2;
+  if (lanes_env >= 1 && lanes_env <= 64 && !(lanes_env & (lanes_env - 1))) lanes = lanes_env;
+  MSOCR_LAUNCH(jpeg_huffman_kernel, dim3((unsigned)((max_intervals + lanes - 1) / lanes), (unsigned)n_pages), dim3(64), 0, s, bytes_dev,
+               static_cast<const ScanDesc*>(descs_dev), bounds_dev, page_base_dev, coef_dev, status_dev, lanes);
   return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
 }
 
 // HOST twin of jpeg_huffman_kernel: the same decode_interval, interval after interval (all pointers host memory).
 extern "C" int msocr_jpeg_entropy_decode_intervals_host(const uint8_t* bytes_host, const void* descs_host, int32_t n_pages,
-                                                        const uint32_t* bounds_host, int16_t* coef_host, int64_t coef_total,
-                                                        int32_t* status_host) {
-  if (!bytes_host || !descs_host || !bounds_host || !coef_host || !status_host || n_pages <= 0 || coef_total <= 0) return MSOCR_E_ARG;
+                                                        const uint32_t* bounds_host, const int64_t* page_base_host, int16_t* coef_host,
+                                                        int64_t coef_total, int32_t* status_host) {
+  if (!bytes_host || !descs_host || !bounds_host || !page_base_host || !coef_host || !status_host || n_pages <= 0 || coef_total <= 0)
+    return MSOCR_E_ARG;
   memset(coef_host, 0, (size_t)coef_total * sizeof(int16_t));
   const ScanDesc* descs = static_cast<const ScanDesc*>(descs_host);
   for (int pg = 0; pg < n_pages; ++pg) {
     const ScanDesc& d = descs[pg];
     status_host[pg] = 0;
-    if (d.coef_base < 0 || d.coef_base + d.info.coef_total > coef_total) return MSOCR_E_ARG;
+    const int64_t coef_base = page_base_host[2 * pg], first_interval = page_base_host[2 * pg + 1];
+    if (coef_base < 0 || coef_base + d.info.coef_total > coef_total || first_interval < 0) return MSOCR_E_ARG;
     const int total = d.mcus_x * d.mcus_y;
     for (int iv = 0; iv < d.n_intervals; ++iv) {
       const int first = iv * d.restart_interval;
       const int n = total - first < d.restart_interval ? total - first : d.restart_interval;
-      if (decode_interval(d.info, d.mcus_x, d.dc, d.ac, d.zigzag, bytes_host, bounds_host[2 * (d.first_interval + iv)],
-                          bounds_host[2 * (d.first_interval + iv) + 1], first, n, coef_host + d.coef_base))
+      if (decode_interval(d.info, d.mcus_x, d.dc, d.ac, d.zigzag, bytes_host + d.bytes_base, bounds_host[2 * (first_interval + iv)],
+                          bounds_host[2 * (first_interval + iv) + 1], first, n, coef_host + coef_base))
         status_host[pg] = 1;
     }
   }

@@ -69,50 +69,57 @@ def decode_jpeg_device(data: bytes, device="cuda", device_entropy=True):
     return _reconstruct(info, torch.from_numpy(coef).to(device, non_blocking=True), device, torch, ops)
 
 
-class ScanBatch:
-    """Host side of the device entropy decode for a batch of parsed streams: descriptors, interval bounds and the files' bytes laid
-    out as msocr_jpeg_entropy_decode_device takes them.  `pages[i]` = index into `descs` of stream i, or -1 (no restart interval,
-    or a marker sequence the host decoder must judge)."""
+def _prepare(ptr, n, info, bytes_base):
+    """Marker walk of one parsed stream -> (descriptor bytes, interval bounds) or None (no restart interval / host decoder's case)."""
+    lib = nat.lib()
+    mcus = (int(info.blocks_w[0]) // int(info.hs[0])) * (int(info.blocks_h[0]) // int(info.vs[0]))
+    d = np.zeros(int(lib.msocr_jpeg_scan_desc_bytes()), dtype=np.uint8)
+    b = np.empty(2 * mcus, dtype=np.uint32)   # at most one interval per MCU
+    niv = int(lib.msocr_jpeg_scan_prepare_host(ptr, n, ctypes.byref(info), bytes_base, d.ctypes.data, b.ctypes.data, mcus))
+    return None if niv <= 0 else (d, b[: 2 * niv])
 
-    def __init__(self, parsed):
-        lib = nat.lib()
-        dsz = int(lib.msocr_jpeg_scan_desc_bytes())
-        self.pages = []
-        self.infos = []
-        descs, bounds, chunks = [], [], []
-        bytes_base = coef_base = first = 0
+
+class ScanBatch:
+    """Host side of the device entropy decode for a batch of parsed streams: descriptors, interval bounds, per-page bases and the
+    files' bytes laid out as msocr_jpeg_entropy_decode_device takes them.  `pages[i]` = index into `descs` of stream i, or -1 (no
+    restart interval, or a marker sequence the host decoder must judge).  `parsed[i]` = (info, ctypes buffer, length) or None;
+    `prepared[i]` (optional) = what `_prepare` returned for stream i with `bytes_base[i]` as its base inside `bytes`."""
+
+    def __init__(self, parsed, prepared=None, bytes_=None):
+        self.pages, self.infos = [], []
+        descs, bounds, chunks, base = [], [], [], []
+        pos = coef_base = first = 0
         self.max_intervals = 0
-        for pr in parsed:
+        for i, pr in enumerate(parsed):
             if pr is None:
                 self.pages.append(-1)
                 continue
             info, buf, n = pr
-            mcus = (int(info.blocks_w[0]) // int(info.hs[0])) * (int(info.blocks_h[0]) // int(info.vs[0]))
-            d = np.zeros(dsz, dtype=np.uint8)
-            b = np.empty(2 * mcus, dtype=np.uint32)   # at most one interval per MCU
-            niv = int(lib.msocr_jpeg_scan_prepare_host(ctypes.addressof(buf), n, ctypes.byref(info), bytes_base, coef_base, first,
-                                                       d.ctypes.data, b.ctypes.data, mcus))
-            if niv <= 0:
+            r = prepared[i] if prepared is not None else _prepare(ctypes.addressof(buf), n, info, pos)
+            if r is None:
                 self.pages.append(-1)
                 continue
             self.pages.append(len(descs))
             self.infos.append((info, coef_base))
-            descs.append(d)
-            bounds.append(b[: 2 * niv])
-            chunks.append(np.frombuffer(buf, dtype=np.uint8, count=n))
-            pad = (-n) % 16
-            if pad:
-                chunks.append(np.zeros(pad, dtype=np.uint8))
-            bytes_base += n + pad
+            descs.append(r[0])
+            bounds.append(r[1])
+            base.append((coef_base, first))
+            if prepared is None:
+                chunks.append(np.frombuffer(buf, dtype=np.uint8, count=n))
+                pad = (-n) % 16
+                if pad:
+                    chunks.append(np.zeros(pad, dtype=np.uint8))
+                pos += n + pad
             coef_base += int(info.coef_total)
-            first += niv
-            self.max_intervals = max(self.max_intervals, niv)
+            first += len(r[1]) // 2
+            self.max_intervals = max(self.max_intervals, len(r[1]) // 2)
         self.n_pages = len(descs)
         self.coef_total = coef_base
         if self.n_pages:
             self.descs = np.stack(descs)
             self.bounds = np.concatenate(bounds)
-            self.bytes = np.concatenate(chunks)
+            self.page_base = np.array(base, dtype=np.int64)
+            self.bytes = bytes_ if prepared is not None else np.concatenate(chunks)
 
 
 def entropy_batch_host_twin(batch: ScanBatch):
@@ -120,24 +127,27 @@ def entropy_batch_host_twin(batch: ScanBatch):
     coef = np.empty(batch.coef_total, dtype=np.int16)
     status = np.empty(batch.n_pages, dtype=np.int32)
     nat.check(nat.lib().msocr_jpeg_entropy_decode_intervals_host(batch.bytes.ctypes.data, batch.descs.ctypes.data, batch.n_pages,
-                                                                  batch.bounds.ctypes.data, coef.ctypes.data, batch.coef_total,
-                                                                  status.ctypes.data), "jpeg_entropy_decode_intervals_host")
+                                                                  batch.bounds.ctypes.data, batch.page_base.ctypes.data, coef.ctypes.data,
+                                                                  batch.coef_total, status.ctypes.data), "jpeg_entropy_decode_intervals_host")
     return coef, status
 
 
-def entropy_batch_device(batch: ScanBatch, device="cuda"):
-    """Uploads the batch's file bytes, descriptors and interval bounds and runs the Huffman stage on the device (current stream)
-    -> (int16 coefficient tensor of the batch, int32 status tensor [n_pages]); nothing is waited for."""
+def entropy_batch_device(batch: ScanBatch, device="cuda", bytes_dev=None):
+    """Uploads the batch's file bytes (unless `bytes_dev` already holds them), descriptors and interval bounds and runs the Huffman
+    stage on the device (current stream) -> (int16 coefficient tensor of the batch, int32 status tensor [n_pages]); nothing is
+    waited for."""
     import torch
 
     from . import ops
-    up = lambda a: torch.from_numpy(a).pin_memory().to(device, non_blocking=True)
-    bytes_dev, descs_dev, bounds_dev = up(batch.bytes), up(batch.descs), up(batch.bounds)
+    up = lambda a: torch.from_numpy(a).to(device)
+    if bytes_dev is None:
+        bytes_dev = torch.from_numpy(batch.bytes).pin_memory().to(device, non_blocking=True)
+    descs_dev, bounds_dev, base_dev = up(batch.descs), up(batch.bounds), up(batch.page_base)
     coef = torch.empty(batch.coef_total, dtype=torch.int16, device=device)
     status = torch.empty(batch.n_pages, dtype=torch.int32, device=device)
     nat.check(nat.lib().msocr_jpeg_entropy_decode_device(bytes_dev.data_ptr(), descs_dev.data_ptr(), batch.n_pages, batch.max_intervals,
-                                                          bounds_dev.data_ptr(), coef.data_ptr(), batch.coef_total, status.data_ptr(),
-                                                          ops._stream()), "jpeg_entropy_decode_device")
+                                                          bounds_dev.data_ptr(), base_dev.data_ptr(), coef.data_ptr(), batch.coef_total,
+                                                          status.data_ptr(), ops._stream()), "jpeg_entropy_decode_device")
     return coef, status
 
 
@@ -161,71 +171,105 @@ def _read_and_parse(path):
     return None if info is None else (info, buf, len(data))
 
 
-def _entropy_into(parsed, coef_ptr):
-    info, buf, n = parsed
-    return nat.lib().msocr_jpeg_entropy_decode_host(ctypes.addressof(buf), n, ctypes.byref(info), coef_ptr)
-
-
 _POOL = None
-_SLOTS = {}   # slot -> [pinned int16 tensor, event of the last upload from it]
+_SLOTS = {}   # slot -> [pinned tensor, event of the last upload from it]; reused across batches (one reader thread at a time)
 
 
-def _slot_buffer(slot, n, torch):
+def _slot_buffer(slot, n, torch, dtype=None):
     ent = _SLOTS.get(slot)
     if ent is None or ent[0].numel() < n:
-        ent = _SLOTS[slot] = [torch.empty(n, dtype=torch.int16).pin_memory(), None]
+        ent = _SLOTS[slot] = [torch.empty(n + n // 4, dtype=dtype or torch.int16).pin_memory(), None]
     elif ent[1] is not None:
         ent[1].synchronize()   # the previous batch's upload from this buffer has left the host
     return ent
 
 
+def _load(path, arr, off, n, want_device):
+    """Worker: file -> its slice of the pinned batch buffer, header parse, marker walk.  -> (info, prepared or None) or None."""
+    try:
+        with open(path, "rb") as f:
+            if f.readinto(memoryview(arr[off: off + n])) != n:
+                return None
+    except OSError:
+        return None
+    if n < 4 or arr[off] != 0xFF or arr[off + 1] != 0xD8:
+        return None
+    info = nat.JpegInfo()
+    ptr = arr.ctypes.data + off
+    if nat.lib().msocr_jpeg_parse_host(ptr, n, ctypes.byref(info)) != 0 or not info.supported:
+        return None
+    return info, (_prepare(ptr, n, info, off) if want_device else None)
+
+
 def read_images_device(paths, device="cuda", device_entropy=None):
     """A batch of files -> list of device RGB tensors (None where read_image must take over).
-    Files with a restart interval: the Huffman stage of the whole batch is ONE kernel launch on the device (`ScanBatch`,
-    `entropy_batch_device`); the host reads the files and walks their markers, nothing else (`device_entropy=False` or
-    MSOCR_JPEG_DEVICE_ENTROPY=0 sends them through the host decoder too).
-    Files without: the entropy decode is one serial bit stream per FILE, but files are independent: the host stages of a batch run
-    on a thread pool (the ctypes calls release the GIL), one page per core, into per-slot PINNED coefficient buffers that live across
-    batches — fresh 9 MB arrays per page made the threads serialise on page faults (40 pages/s against 57 for the serial loop), and
-    pinned memory lets the upload run asynchronously.  This thread uploads and launches the reconstruction page by page as the
-    decodes finish."""
+    A thread pool reads every file into its slice of ONE pinned batch buffer (reused across batches), parses its headers and walks
+    its markers (the ctypes calls release the GIL).  Files with a restart interval: the buffer is uploaded as it is and the Huffman
+    stage of the whole batch is ONE kernel launch (`entropy_batch_device`, one thread per interval) — unless the intervals are so
+    long that the serial chain inside one of them would take longer than a host core needs for the file
+    (MSOCR_JPEG_DEVICE_MAX_INTERVAL bytes, default 8192: 1.8 ms per KB of interval on the device against ~15 ms per 1.6 MB file on a
+    host core; `device_entropy=True` / False or MSOCR_JPEG_DEVICE_ENTROPY=1 / 0 force one path).
+    Files without: the entropy decode is one serial bit stream per FILE, but files are independent: the pool decodes one page per
+    core into per-slot PINNED coefficient buffers that live across batches (fresh 9 MB arrays per page made the threads serialise
+    on page faults), this thread uploads and launches the reconstruction page by page as the decodes finish."""
     global _POOL
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
     from . import ops
-    if device_entropy is None:
-        device_entropy = os.environ.get("MSOCR_JPEG_DEVICE_ENTROPY", "1") != "0"
+    env = os.environ.get("MSOCR_JPEG_DEVICE_ENTROPY")
+    if device_entropy is None and env is not None:
+        device_entropy = env != "0"
+    max_iv = int(os.environ.get("MSOCR_JPEG_DEVICE_MAX_INTERVAL", "8192"))
     if _POOL is None:
         _POOL = ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 2) - 1)), thread_name_prefix="msocr-jpeg")
-    parsed = list(_POOL.map(_read_and_parse, paths)) if len(paths) > 1 else [_read_and_parse(p) for p in paths]
+    sizes = [os.path.getsize(p) if isinstance(p, (str, os.PathLike)) and os.path.isfile(p) else -1 for p in paths]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (max(n, 0) + 15) // 16 * 16
+    if total == 0:
+        return [None] * len(paths)
+    ent = _slot_buffer("bytes", total, torch, torch.uint8)
+    arr = ent[0].numpy()
+    want = device_entropy is not False
+    jobs = [(_POOL.submit(_load, p, arr, o, n, want) if n >= 0 else None) for p, o, n in zip(paths, offs, sizes)]
+    loaded = [j.result() if j is not None else None for j in jobs]
     on_dev = {}
-    if device_entropy and any(pr is not None for pr in parsed):
-        batch = ScanBatch(parsed)
+    if want:
+        prepared = [None if (r is None or r[1] is None) else r[1] for r in loaded]
+        if device_entropy is None:   # the policy: no interval of the page longer than max_iv bytes
+            prepared = [None if (r is None or int((r[1][1::2] - r[1][0::2]).max()) > max_iv) else r for r in prepared]
+        parsed = [None if r is None else (r[0], None, n) for r, n in zip(loaded, sizes)]
+        batch = ScanBatch(parsed, prepared, arr)
         if batch.n_pages:
-            coef, status = entropy_batch_device(batch, device)
+            bytes_dev = ent[0][:total].to(device, non_blocking=True)
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+            coef, status = entropy_batch_device(batch, device, bytes_dev)
             imgs = [_reconstruct(info, coef[base:], device, torch, ops) for info, base in batch.infos]
             bad = status.cpu().numpy()   # the one wait of this path: a bad stream must go to the host reader, as the host decoder's verdict would
             on_dev = {i: (imgs[k] if bad[k] == 0 else None) for i, k in enumerate(batch.pages) if k >= 0}
+    lib = nat.lib()
     futs = []
-    for i, pr in enumerate(parsed):
-        if pr is None or i in on_dev:
+    for i, r in enumerate(loaded):
+        if r is None or i in on_dev:
             futs.append(None)
             continue
-        ent = _slot_buffer(i, int(pr[0].coef_total), torch)   # main thread: allocation / pinning is not done from the workers
-        futs.append((_POOL.submit(_entropy_into, pr, ent[0].data_ptr()), ent))
+        slot = _slot_buffer(i, int(r[0].coef_total), torch)   # main thread: allocation / pinning is not done from the workers
+        futs.append((_POOL.submit(lib.msocr_jpeg_entropy_decode_host, arr.ctypes.data + offs[i], sizes[i], ctypes.byref(r[0]), slot[0].data_ptr()), slot))
     out = []
-    for i, (pr, f) in enumerate(zip(parsed, futs)):
+    for i, (r, f) in enumerate(zip(loaded, futs)):
         if i in on_dev:
             out.append(on_dev[i])
             continue
         if f is None or f[0].result() != 0:
             out.append(None)
             continue
-        info, ent = pr[0], f[1]
-        coef_dev = ent[0][: int(info.coef_total)].to(device, non_blocking=True)
-        ent[1] = torch.cuda.Event()
-        ent[1].record()
+        info, slot = r[0], f[1]
+        coef_dev = slot[0][: int(info.coef_total)].to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
         out.append(_reconstruct(info, coef_dev, device, torch, ops))
     return out
 

@@ -35,11 +35,12 @@ static int run_one(const std::vector<uint8_t>& d, long* accepted) {
       std::vector<uint64_t> desc((size_t)(msocr_jpeg_scan_desc_bytes() + 7) / 8);
       const int64_t cap = info.coef_total / 64 + 1;
       std::vector<uint32_t> bounds((size_t)(2 * cap));
-      const int64_t niv = msocr_jpeg_scan_prepare_host(buf, (int64_t)d.size(), &info, 0, 0, 0, desc.data(), bounds.data(), cap);
+      const int64_t niv = msocr_jpeg_scan_prepare_host(buf, (int64_t)d.size(), &info, 0, desc.data(), bounds.data(), cap);
       if (niv > 0) {
         std::vector<int16_t> coef2((size_t)info.coef_total);
         int32_t status = 0;
-        if (msocr_jpeg_entropy_decode_intervals_host(buf, desc.data(), 1, bounds.data(), coef2.data(), info.coef_total, &status) != 0) return 1;
+        const int64_t page_base[2] = {0, 0};
+        if (msocr_jpeg_entropy_decode_intervals_host(buf, desc.data(), 1, bounds.data(), page_base, coef2.data(), info.coef_total, &status) != 0) return 1;
         if ((status != 0) != (serial_rc != 0)) { fprintf(stderr, "verdicts differ: intervals %d serial %d\n", status, serial_rc); return 1; }
         if (serial_rc == 0 && memcmp(coef.data(), coef2.data(), coef.size() * 2) != 0) { fprintf(stderr, "coefficients differ\n"); return 1; }
         ++*intervals;

@@ -421,7 +421,7 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
             info, ref = ingest.jpeg_coefficients(d)
             assert np.array_equal(coef[batch.infos[k][1]: batch.infos[k][1] + int(info.coef_total)], ref), i
     # (b) the batch reader: device Huffman + reconstruction == PIL for every file, with and without restart intervals
-    got = ingest.read_images_device(files)
+    got = ingest.read_images_device(files, device_entropy=True)
     for d, g in zip(datas, got):
         assert g is not None and np.array_equal(g.cpu().numpy(), np.array(Image.open(io.BytesIO(d)).convert("RGB")))
     assert np.array_equal(ingest.decode_jpeg_device(datas[0]).cpu().numpy(), ingest.decode_jpeg_device(datas[0], device_entropy=False).cpu().numpy())
@@ -434,7 +434,7 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
         for _ in range(3):
             t[int(rng.integers(sos + 14, len(t) - 2))] = int(rng.integers(0, 255))
         (tmp_path / "bad.jpg").write_bytes(bytes(t))
-        r = ingest.read_images_device([files[0], str(tmp_path / "bad.jpg"), files[2]])
+        r = ingest.read_images_device([files[0], str(tmp_path / "bad.jpg"), files[2]], device_entropy=True)
         ref = ingest.decode_jpeg_host(bytes(t))
         assert (r[1] is None) == (ref is None)
         if ref is not None:
@@ -442,14 +442,18 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
         verdicts.add(ref is None)
         assert np.array_equal(r[0].cpu().numpy(), got[0].cpu().numpy()) and np.array_equal(r[2].cpu().numpy(), got[2].cpu().numpy())
     assert verdicts == {True, False}
-    # (d) bench-sized pages: 4 x 2048 x 1536, one interval per MCU row
+    # (d) bench-sized pages: 4 x 2048 x 1536, one interval per MCU row (12 KB intervals: the default policy sends them to the host
+    #     decoder, device_entropy=True to the kernel — spread one interval per wave) and 16-MCU intervals (the kernel by default)
     pages = [synth.synth_page(70 + k, 2048, 1536)[0] for k in range(4)]
-    big = []
-    for k, pg in enumerate(pages):
-        Image.fromarray(pg).save(tmp_path / f"p{k}.jpg", format="JPEG", quality=90, restart_marker_rows=1)
-        big.append(str(tmp_path / f"p{k}.jpg"))
-    for f, g in zip(big, ingest.read_images_device(big)):
-        assert np.array_equal(g.cpu().numpy(), np.array(Image.open(f).convert("RGB")))
+    for kw in ({"restart_marker_rows": 1}, {"restart_marker_blocks": 16}):
+        big = []
+        for k, pg in enumerate(pages):
+            Image.fromarray(pg).save(tmp_path / f"p{k}.jpg", format="JPEG", quality=90, **kw)
+            big.append(str(tmp_path / f"p{k}.jpg"))
+        exp = [np.array(Image.open(f).convert("RGB")) for f in big]
+        for forced in (True, None, False):
+            for e, g in zip(exp, ingest.read_images_device(big, device_entropy=forced)):
+                assert np.array_equal(g.cpu().numpy(), e), (kw, forced)
 
 
 def test_device_jpeg_ingest(gpu, tmp_path):

@@ -21,8 +21,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     pages = [synth.synth_page(100 + k, 2048, 1536)[0] for k in range(n)]
     with tempfile.TemporaryDirectory(prefix="msocr_jt_", dir="/tmp") as td:
-        for label, kw in (("rows=1", {"restart_marker_rows": 1}), ("rows=4", {"restart_marker_rows": 4}), ("blocks=16", {"restart_marker_blocks": 16}),
-                          ("blocks=4", {"restart_marker_blocks": 4})):
+        for label, kw in (("rows=1", {"restart_marker_rows": 1}), ("rows=4", {"restart_marker_rows": 4}), ("blocks=32", {"restart_marker_blocks": 32}),
+                          ("blocks=16", {"restart_marker_blocks": 16}), ("blocks=4", {"restart_marker_blocks": 4})):
             paths = []
             for k, pg in enumerate(pages):
                 paths.append(os.path.join(td, f"{label}_{k}.jpg"))
@@ -44,8 +44,11 @@ def main():
             torch.cuda.synchronize()
             assert not status.cpu().numpy().any()
             t3 = time.perf_counter()
+            ingest.read_images_device(paths, device_entropy=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
             for _ in range(3):
-                out = ingest.read_images_device(paths)
+                out = ingest.read_images_device(paths, device_entropy=True)
             torch.cuda.synchronize()
             t4 = time.perf_counter()
             print(f"{label}: {size / 1e3:.0f} kB/page, {batch.max_intervals} intervals/page; read+parse {1e3 * (t1 - t0):.1f} ms, marker walk + layout "
