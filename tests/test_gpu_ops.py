@@ -244,6 +244,8 @@ def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
 FUSED64_CASES = [
     # N, H, W, Cout, relu, residual, pool2     (Cin = 64)
     (3, 32, 100, 128, True, False, True),    # TRBA conv0b + MaxPool2d(2, 2)
+    (41, 32, 100, 128, True, False, True),   # 16 400 tiles: 129 workgroup rows of 128 tiles, the last one partial
+    (2, 30, 44, 64, False, True, False),     # residual without ReLU, partial tiles on the H axis
     (2, 16, 50, 128, True, False, True),
     (1, 4, 6, 96, True, False, True),        # one tile row, 3 cout blocks
     (2, 8, 12, 64, True, True, False),       # ResNet-50 layer1 style, residual
