@@ -23,6 +23,10 @@
 // Cells of q x q pixels in row-major order == np.unique(axis=0) order of the quantised (y, x)
 // pairs (utils.py:349-356).  A cell is a candidate iff any of its pixels has score > thr
 // (strict, f32).  Row = 4 vertices (x*s + dx*s, y*s + dy*s) + score at the cell CENTRE.
+// Hardening (round 4; the reference has no defined behaviour here — NaN polygons run into numba / cv2): a candidate whose centre
+// score or any of whose eight offsets is NaN, infinite or >= 1e7 in magnitude is DROPPED here, the one funnel every later kernel
+// (LANMS, box filters, reading order, crops) is fed from: sorts, bucket indices and float -> int conversions downstream then only
+// ever see finite coordinates below 2^24.  Maps a network can produce are unaffected.
 __global__ __launch_bounds__(1024) void east_decode_kernel(const float* __restrict__ score, const float* __restrict__ geo, int H,
                                                             int W, float thr, double scale, int q, float* __restrict__ cand,
                                                             int32_t* __restrict__ count, int max_cand) {
@@ -47,6 +51,14 @@ __global__ __launch_bounds__(1024) void east_decode_kernel(const float* __restri
       cx = cell - cy * Wq;
       for (int dy = 0; dy < q; ++dy)
         for (int dx = 0; dx < q; ++dx) on |= sm[(long)(cy * q + dy) * W + cx * q + dx] > thr;
+      if (on) {
+        const int y = q > 1 ? cy * q + q / 2 : cy, x = q > 1 ? cx * q + q / 2 : cx;
+        const float* g = gm + ((long)y * W + x) * 8;
+        bool sane = fabsf(sm[(long)y * W + x]) < 1.0e7f;   // false for NaN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sane &= fabsf(g[i]) < 1.0e7f;
+        on = sane;
+      }
     }
     const unsigned long long bal = __ballot(on);
     const int wpre = __popcll(bal & ((1ull << lane) - 1ull));

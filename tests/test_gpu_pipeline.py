@@ -169,6 +169,51 @@ def test_checkpoint_files_load_like_the_reference(gpu, tmp_path):
         det_f.predict(str(tmp_path / "missing.jpg"))
 
 
+def test_non_finite_maps_are_dropped_at_decode_not_propagated(gpu):
+    """Round 4 hardening: NaN / Inf / absurd (>= 1e7) values in the score or geometry maps — a corrupted checkpoint, an overflow
+    upstream — never reach LANMS, the box filters, the reading order or the crop kernels: the decode kernel drops such candidates,
+    and the page's result equals the result of the same maps with those cells switched off.  (The reference has no defined
+    behaviour here: NaN polygons run into numba / cv2.)  Checked at the decode entry point first, then through the whole pipeline."""
+    from manuscript_ocr_amd import Pipeline, ops, synth
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    H, W = 256, 384
+    pages, maps = [], []
+    for seed in (81, 82):
+        pg, rects = synth.synth_page(seed, H, W)
+        pages.append(pg)
+        maps.append(synth.synth_maps(rects, (H, W), (H // 4, W // 4), seed))
+    score = torch.from_numpy(np.stack([m[0] for m in maps])).cuda()
+    geo = torch.from_numpy(np.stack([m[1] for m in maps])).cuda()
+    on = (score > 0.5).nonzero()
+    assert len(on) > 60
+    g = torch.Generator().manual_seed(5)
+    pick = on[torch.randperm(len(on), generator=g)[:24]]
+    bad_s, bad_g, off_s = score.clone(), geo.clone(), score.clone()
+    poison = [float("nan"), float("inf"), -float("inf"), 3.0e7, -1.0e30, float("nan")]
+    for k, (n, y, x) in enumerate(pick.tolist()):
+        if k % 4 == 3:
+            bad_s[n, y, x] = float("inf") if k % 8 == 3 else float("nan")   # NaN score: never above threshold anyway
+        else:
+            bad_g[n, y, x, k % 8] = poison[k % 6]
+        off_s[n, y, x] = 0.0
+    cap = (H // 4) * (W // 4)
+    c_bad, n_bad = ops.east_decode(bad_s, bad_g, 0.5, 4.0, 1, cap)
+    c_off, n_off = ops.east_decode(off_s, geo, 0.5, 4.0, 1, cap)
+    assert torch.equal(n_bad, n_off) and int(n_bad.sum()) == len(on) - 24
+    for n in range(2):
+        k = int(n_bad[n])
+        assert torch.equal(c_bad[n, :k], c_off[n, :k]) and bool(torch.isfinite(c_bad[n, :k]).all())
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    # quantization=1: every map pixel is its own cell, so "the poisoned cell is dropped" == "its score is switched off" exactly
+    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), target_size=(W, H), device="cuda", quantization=1),
+                    TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda"))
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    a = pipe.predict_batch(pages, _maps_override=(bad_s, bad_g))
+    b = pipe.predict_batch(pages, _maps_override=(off_s, geo))
+    assert [key(p) for p in a] == [key(p) for p in b] and sum(len(key(p)) for p in a) > 4
+
+
 def test_empty_and_ragged_inputs(gpu):
     """No pixel above threshold -> empty Page, recogniser untouched; empty crop list -> []; unequal page sizes in one
     batch are processed (one group per size since round 4: test_ragged_page_batches_equal_per_page_calls) while a stacked
