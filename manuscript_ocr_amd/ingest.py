@@ -222,7 +222,9 @@ def read_images_device(paths, device="cuda", device_entropy=None):
         device_entropy = env != "0"
     max_iv = int(os.environ.get("MSOCR_JPEG_DEVICE_MAX_INTERVAL", "8192"))
     if _POOL is None:
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 2) - 1)), thread_name_prefix="msocr-jpeg")
+        # one process per GPU: the ranks of a node share its cores (LOCAL_WORLD_SIZE is set by torch.distributed.run)
+        share = (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(32, share - 1)), thread_name_prefix="msocr-jpeg")
     sizes = [os.path.getsize(p) if isinstance(p, (str, os.PathLike)) and os.path.isfile(p) else -1 for p in paths]
     offs, total = [], 0
     for n in sizes:
