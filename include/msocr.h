@@ -121,6 +121,22 @@ int msocr_winograd42_gemm_split(const msocr_conv_desc* d, const void* u_planes, 
 int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
                                    const void* residual, void* out, void* workspace, void* stream);
 
+/* F(4,3) x F(4,3) on the interpolation points {0, +-3/2, +-2/3, inf} (round 4): 36 transform points per 4 x 4 outputs — 2.25
+ * multiplies and workspace words per output instead of the tall form's 3 — at the tall form's rounding error (the textbook points
+ * {0, +-1, +-2} would cost 4.7x).  Same contract as the msocr_*winograd42* entry points: workspace =
+ * msocr_conv3x3_winograd44_workspace_bytes (V [36][tiles][Cin] f32 + Mw [36][tiles][Cout] f32, tiles = N ceil(H/4) ceil(W/4));
+ * u_planes = K-tile-major bf16 planes ([3][36][Cin/32][Cout][32], msocr_split_bf16x3_ktile_host) of msocr_winograd44_weights_host's
+ * [36][Cout][Cin] f32 output (HOST function, f64, rounded once); Cin % 32 == 0, Cout % 64 == 0; the 36 GEMMs run with split
+ * operands on the bf16 matrix pipes.  The three stages are also callable one by one (same workspace). */
+int64_t msocr_conv3x3_winograd44_workspace_bytes(const msocr_conv_desc* d);
+int msocr_winograd44_weights_host(const float* w_khwc_host, int Cout, int Cin, float* u_out_host);
+int msocr_winograd44_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream);
+int msocr_winograd44_gemm_split(const msocr_conv_desc* d, const void* u_planes, void* workspace, void* stream);
+int msocr_winograd44_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias, const void* residual,
+                                      void* out, void* stream);
+int msocr_conv3x3_winograd44_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                   const void* residual, void* out, void* workspace, void* stream);
+
 /* Cin == 64: the tall Winograd form with the 24 transform-domain GEMMs (K = 64) and the output transform fused in one kernel, so
  * Mw never reaches HBM (unfused, a 64-channel layer is HBM-bound on Mw).  workspace holds V only
  * (msocr_conv3x3_winograd42_fused_workspace_bytes; -1 = unsupported: Cin != 64, Cout % 32, or POOL2 with odd H / W or a residual).

@@ -64,6 +64,12 @@ _SIGS = {
     "msocr_conv2d_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_gemm_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd42_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd44_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "msocr_winograd44_weights_host": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "msocr_winograd44_input_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd44_gemm_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp]),
+    "msocr_winograd44_output_transform": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "msocr_conv3x3_winograd44_split": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_conv3x3_winograd42_fused_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "msocr_conv3x3_winograd42_fused": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "msocr_winograd42_fused_gemm_output": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

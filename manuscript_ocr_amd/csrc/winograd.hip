@@ -390,6 +390,228 @@ extern "C" int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const vo
 }
 
 // =====================================================================================================================
+// F(4,3) x F(4,3) on ACCURACY-CHOSEN interpolation points (round 4): 36 transform points per 4 x 4 outputs = 2.25 multiplies and
+// workspace words per output instead of the tall form's 3.  With the textbook points {0, +-1, +-2, inf} the square form's rounding
+// error is 4.7x the tall form's and cannot pass the f64 arbitration of the tolerances (tests/test_gpu_f64.py); with
+// {0, +-3/2, +-2/3, inf} — reciprocal pairs keep the Vandermonde entries within [8/27, 27/8] — an f32 simulation of the whole
+// pipeline of transforms measures 1.05x the tall form's error (and 0.5x for the tall form itself on these points;
+// tools/winograd_points.py, profiles/r04_winograd_points.txt).  Matrices (Cook-Toom, wincnn scaling: G carries 1 / prod(a_j - a_l)):
+//   B^T d:  r0 = d0 - 97/36 d2 + d4          r5 = d1 - 97/36 d3 + d5
+//           e1 = d4 - 4/9 d2,  o1 = 3/2 d3 - 2/3 d1:   r1 = e1 + o1,  r2 = e1 - o1        (points +-3/2)
+//           e2 = d4 - 9/4 d2,  o2 = 2/3 d3 - 3/2 d1:   r3 = e2 + o2,  r4 = e2 - o2        (points +-2/3)
+//   A^T m:  y0 = m0 + (m1 + m2) + (m3 + m4)             y1 = 3/2 (m1 - m2) + 2/3 (m3 - m4)
+//           y2 = 9/4 (m1 + m2) + 4/9 (m3 + m4)          y3 = 27/8 (m1 - m2) + 8/27 (m3 - m4) + m5
+//   G (host, f64): rows [1,0,0], [8,+-12,18]/65, [-81/2,-+27,-18]/65, [0,0,1].
+//   V[(xi*6+nu)][tile][c], xi = 0..5 (H axis), nu = 0..5 (W axis); Mw likewise; U from msocr_winograd44_weights_host.
+// Reference layers: the 3x3 / stride 1 / pad 1 convolutions of seresnet31.py:37-67 and of torchvision's Bottleneck (east.py:13-30).
+// =====================================================================================================================
+__device__ __forceinline__ void wino44_bt(const f32x4 d[6], f32x4 r[6]) {
+  constexpr float k97_36 = 97.0f / 36.0f, k4_9 = 4.0f / 9.0f, k9_4 = 2.25f, k3_2 = 1.5f, k2_3 = 2.0f / 3.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r[0][e] = fmaf(-k97_36, d[2][e], d[0][e]) + d[4][e];
+    r[5][e] = fmaf(-k97_36, d[3][e], d[1][e]) + d[5][e];
+    const float e1 = fmaf(-k4_9, d[2][e], d[4][e]), o1 = fmaf(k3_2, d[3][e], -k2_3 * d[1][e]);
+    const float e2 = fmaf(-k9_4, d[2][e], d[4][e]), o2 = fmaf(k2_3, d[3][e], -k3_2 * d[1][e]);
+    r[1][e] = e1 + o1; r[2][e] = e1 - o1;
+    r[3][e] = e2 + o2; r[4][e] = e2 - o2;
+  }
+}
+__device__ __forceinline__ void wino44_at(const f32x4 m[6], f32x4 y[4]) {
+  constexpr float k3_2 = 1.5f, k2_3 = 2.0f / 3.0f, k9_4 = 2.25f, k4_9 = 4.0f / 9.0f, k27_8 = 3.375f, k8_27 = 8.0f / 27.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float p12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], p34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+    y[0][e] = (m[0][e] + p12) + p34;
+    y[1][e] = fmaf(k3_2, d12, k2_3 * d34);
+    y[2][e] = fmaf(k9_4, p12, k4_9 * p34);
+    y[3][e] = fmaf(k27_8, d12, k8_27 * d34) + m[5][e];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino44_input_kernel(const float* __restrict__ in, long sN, long sH, long sW, int C,
+                                                            WinoGeom g, float* __restrict__ V) {
+  const int cch = C >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
+  const float* base = in + (long)n * sN + c;
+  // W axis first (B^T per row as the row is loaded), then the H transform per column
+  f32x4 q[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int hi = h0 + i;
+    const bool okh = (unsigned)hi < (unsigned)g.H;
+    f32x4 d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int wi = w0 + j;
+      const bool ok = okh && (unsigned)wi < (unsigned)g.W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + (long)hi * sH + (long)wi * sW : base);
+      d[j] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    wino44_bt(d, q[i]);
+  }
+  const long plane = g.Mt * (long)C;
+  float* o = V + t * (long)C + c;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const f32x4 col[6] = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j]};
+    f32x4 v[6];
+    wino44_bt(col, v);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(o + (i * 6 + j) * plane) = v[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restrict__ Mw, int Cout, WinoGeom g,
+                                                             const float* __restrict__ bias, const float* __restrict__ res,
+                                                             long res_ld, int relu, float* __restrict__ out, long out_ld) {
+  const int cch = Cout >> 2;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = gid / cch;
+  const int c = (int)(gid - t * cch) << 2;
+  if (t >= g.Mt) return;
+  const int tw = (int)(t % g.TW);
+  const long r = t / g.TW;
+  const int th = (int)(r % g.TH);
+  const int n = (int)(r / g.TH);
+  const long plane = g.Mt * (long)Cout;
+  const float* mp = Mw + t * (long)Cout + c;
+  // H axis first (A^T per column as the column is loaded), then A^T along W
+  f32x4 s[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    f32x4 m[6], y[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + (i * 6 + j) * plane);
+    wino44_at(m, y);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s[a][j] = y[a];
+  }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int ho = 4 * th + a;
+    if (ho >= g.H) continue;
+    f32x4 y[4];
+    wino44_at(s[a], y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = 4 * tw + j;
+      if (wo >= g.W) continue;
+      const long pix = ((long)n * g.H + ho) * g.W + wo;
+      f32x4 v = y[j] + b;
+      if (res) v += *reinterpret_cast<const f32x4*>(res + pix * res_ld + c);
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+  }
+}
+
+static bool wino44_geom(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino_geom(d, g)) return false;
+  g->TH = (d->H + 3) / 4;
+  g->TW = (d->W + 3) / 4;
+  g->Mt = (long)d->N * g->TH * g->TW;
+  return 36 * g->Mt * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) <= 0x3fffffffffffL;
+}
+
+extern "C" int64_t msocr_conv3x3_winograd44_workspace_bytes(const msocr_conv_desc* d) {
+  WinoGeom g;
+  if (!wino44_geom(d, &g)) return -1;
+  return 36 * g.Mt * ((int64_t)d->Cin + d->Cout) * (int64_t)sizeof(float);
+}
+
+static int wino44_check(const msocr_conv_desc* d, WinoGeom* g) {
+  if (!wino44_geom(d, g)) return MSOCR_E_ARG;
+  if (d->in_sN % 4 || d->in_sH % 4 || d->in_sW % 4 || d->out_ld % 4 || d->out_ld < d->Cout) return MSOCR_E_ARG;
+  return MSOCR_OK;
+}
+
+extern "C" int msocr_winograd44_input_transform(const msocr_conv_desc* d, const void* in, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino44_check(d, &g) != MSOCR_OK || !in || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)in | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const long nb_in = (g.Mt * (d->Cin / 4) + 255) / 256;
+  if (nb_in > 0x7fffffffL) return MSOCR_E_ARG;
+  MSOCR_LAUNCH(wino44_input_kernel, dim3((unsigned)nb_in), dim3(256), 0, (hipStream_t)stream, (const float*)in, (long)d->in_sN,
+               (long)d->in_sH, (long)d->in_sW, d->Cin, g, (float*)workspace);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+// The 36 transform-domain GEMMs on the bf16 matrix pipes with exactly split operands (conv_split_pp.hip): V split in registers,
+// U given as K-tile-major bf16 planes [3][36][Cin/32][Cout][32] of msocr_winograd44_weights_host's output.
+extern "C" int msocr_winograd44_gemm_split(const msocr_conv_desc* d, const void* u_planes, void* workspace, void* stream) {
+  WinoGeom g;
+  if (wino44_check(d, &g) != MSOCR_OK || !u_planes || !workspace || d->Cin % 32 || d->Cout % 64) return MSOCR_E_ARG;
+  float* V = (float*)workspace;
+  return msocr_internal_gemm_split_batched(V, (const uint16_t*)u_planes, V + 36 * g.Mt * (long)d->Cin, g.Mt, d->Cout, d->Cin, 36,
+                                           (hipStream_t)stream);
+}
+
+extern "C" int msocr_winograd44_output_transform(const msocr_conv_desc* d, const void* workspace, const float* bias,
+                                                 const void* residual, void* out, void* stream) {
+  WinoGeom g;
+  if (wino44_check(d, &g) != MSOCR_OK || !out || !workspace) return MSOCR_E_ARG;
+  if (((uintptr_t)out | (uintptr_t)workspace) & 15) return MSOCR_E_ARG;
+  const bool has_res = (d->flags & MSOCR_CONV_RESIDUAL) != 0;
+  if (has_res && (!residual || d->res_ld % 4 || d->res_ld < d->Cout || ((uintptr_t)residual & 15))) return MSOCR_E_ARG;
+  if (bias && ((uintptr_t)bias & 15)) return MSOCR_E_ARG;
+  const long nb_out = (g.Mt * (d->Cout / 4) + 255) / 256;
+  if (nb_out > 0x7fffffffL) return MSOCR_E_ARG;
+  const float* Mw = (const float*)workspace + 36 * g.Mt * (long)d->Cin;
+  MSOCR_LAUNCH(wino44_output_kernel, dim3((unsigned)nb_out), dim3(256), 0, (hipStream_t)stream, Mw, d->Cout, g, bias,
+               has_res ? (const float*)residual : nullptr, (long)d->res_ld, (d->flags & MSOCR_CONV_RELU) ? 1 : 0, (float*)out,
+               (long)d->out_ld);
+  return hipGetLastError() == hipSuccess ? MSOCR_OK : MSOCR_E_LAUNCH;
+}
+
+extern "C" int msocr_conv3x3_winograd44_split(const msocr_conv_desc* d, const void* in, const void* u_planes, const float* bias,
+                                              const void* residual, void* out, void* workspace, void* stream) {
+  if (!u_planes) return MSOCR_E_ARG;
+  int rc = msocr_winograd44_input_transform(d, in, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  rc = msocr_winograd44_gemm_split(d, u_planes, workspace, stream);
+  if (rc != MSOCR_OK) return rc;
+  return msocr_winograd44_output_transform(d, workspace, bias, residual, out, stream);
+}
+
+// U[xi*6+nu][co][c] = sum_{kh,kw} G[xi][kh] G[nu][kw] w[co][kh][kw][c] for the points {0, 3/2, -3/2, 2/3, -2/3, inf}, f64, rounded once.
+// HOST function like msocr_winograd42_weights_host.
+extern "C" int msocr_winograd44_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {
+  if (!w_khwc || !u_out || Cout <= 0 || Cin <= 0) return MSOCR_E_ARG;
+  static const double G[6][3] = {{1.0, 0.0, 0.0},
+                                 {8.0 / 65, 12.0 / 65, 18.0 / 65},     {8.0 / 65, -12.0 / 65, 18.0 / 65},
+                                 {-81.0 / 130, -27.0 / 65, -18.0 / 65}, {-81.0 / 130, 27.0 / 65, -18.0 / 65},
+                                 {0.0, 0.0, 1.0}};
+  const long plane = (long)Cout * Cin;
+  for (int co = 0; co < Cout; ++co) {
+    const float* w = w_khwc + (long)co * 9 * Cin;
+    for (int c = 0; c < Cin; ++c) {
+      double gw[6][3];  // G g
+      for (int xi = 0; xi < 6; ++xi)
+        for (int kw = 0; kw < 3; ++kw)
+          gw[xi][kw] = G[xi][0] * w[(0 * 3 + kw) * Cin + c] + G[xi][1] * w[(1 * 3 + kw) * Cin + c] + G[xi][2] * w[(2 * 3 + kw) * Cin + c];
+      for (int xi = 0; xi < 6; ++xi)
+        for (int nu = 0; nu < 6; ++nu)
+          u_out[(xi * 6 + nu) * plane + (long)co * Cin + c] =
+              (float)(gw[xi][0] * G[nu][0] + gw[xi][1] * G[nu][1] + gw[xi][2] * G[nu][2]);
+    }
+  }
+  return MSOCR_OK;
+}
+
+// =====================================================================================================================
 // Cin == 64: the tall form with the 24 GEMMs AND the output transform in ONE kernel (Mw never reaches HBM).
 // With 64 input channels the transform-domain GEMMs have K = 64 and the unfused form is HBM-bound on Mw (3x the layer's output:
 // TRBA conv0b would move 132 GB per step against 19 GB for the direct convolution).  Here a workgroup owns 32 tiles x 32 output

@@ -102,6 +102,17 @@ def _tall_pays(H):
     return 24 * (-(-H // 4)) < 16 * (-(-H // 2))
 
 
+# Square form F(4,3) x F(4,3) on the points {0, +-3/2, +-2/3, inf} (csrc/winograd.hip, wino44_*; round 4): 36 points per 4x4 outputs =
+# 2.25 multiplies and workspace words per output instead of 3, at the tall form's rounding error.  Split-operand GEMMs only
+# (precision="fp32" default); taken where it is cheaper than the tall form for the map width: 36 * ceil(W/4) < 24 * ceil(W/2).
+# MSOCR_WINO_SQUARE=0 keeps the tall form.
+WINOGRAD_SQUARE = int(os.environ.get("MSOCR_WINO_SQUARE", "1"))
+
+
+def _square_pays(W):
+    return 36 * (-(-W // 4)) < 24 * (-(-W // 2))
+
+
 # Cin == 64 layers (TRBA conv0b, the 3x3s of ResNet-50 layer1): tall Winograd with the 24 GEMMs (K = 64) and the output transform
 # fused in one kernel (csrc/winograd.hip, wino42_fused64_kernel) — unfused, such a layer is HBM-bound on Mw.  conv2d(pool2=True)
 # folds the following 2x2/2 max-pool into the same kernel.  MSOCR_WINO_FUSED64=0 keeps these layers on the direct kernel.
@@ -194,6 +205,10 @@ def attach_winograd(w, split=None):
     w._msocr_wino42 = u42.to(w.device)
     if (SPLIT_BF16X3 if split is None else split) and Cin % 32 == 0 and Cout % 64 == 0:
         w._msocr_wino42_split = split_planes_ktile(u42, 24, Cout).to(w.device)  # [3][24][Cin/32][Cout][32] bf16
+        if WINOGRAD_SQUARE:
+            u44 = torch.empty((36, Cout, Cin), dtype=torch.float32)
+            nat.check(nat.lib().msocr_winograd44_weights_host(wh.data_ptr(), Cout, Cin, u44.data_ptr()), "winograd44_weights_host")
+            w._msocr_wino44_split = split_planes_ktile(u44, 36, Cout).to(w.device)  # [3][36][Cin/32][Cout][32] bf16
     return w
 
 
@@ -305,6 +320,11 @@ def conv2d(x, w, bias, stride=(1, 1), pad=(0, 0), relu=False, residual=None, out
             if up is not None and SPLIT_BF16X3:  # the 24 GEMMs on the bf16 pipes with exactly split operands
                 u, name, whole, st_gemm = up, "winograd42_split", L.msocr_conv3x3_winograd42_split, L.msocr_winograd42_gemm_split
             TH, TW, npts = (Ho + 3) // 4, (Wo + 1) // 2, 24
+            up44 = getattr(w, "_msocr_wino44_split", None)
+            if up44 is not None and SPLIT_BF16X3 and WINOGRAD_SQUARE and _square_pays(W):
+                u, name, f_ws, whole = up44, "winograd44_split", L.msocr_conv3x3_winograd44_workspace_bytes, L.msocr_conv3x3_winograd44_split
+                st_in, st_gemm, st_out = L.msocr_winograd44_input_transform, L.msocr_winograd44_gemm_split, L.msocr_winograd44_output_transform
+                TH, TW, npts = (Ho + 3) // 4, (Wo + 3) // 4, 36
         else:
             name, f_ws, whole = "winograd", L.msocr_conv3x3_winograd_workspace_bytes, L.msocr_conv3x3_winograd
             st_in, st_gemm, st_out = L.msocr_winograd_input_transform, L.msocr_winograd_gemm, L.msocr_winograd_output_transform

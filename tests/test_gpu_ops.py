@@ -212,6 +212,7 @@ def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
     """Tall Winograd with the 24 transform-domain GEMMs on the split-operand kernel against an f64 convolution: 2e-5 bound, within
     2x of the exact-f32 Winograd path's own error."""
     monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
+    monkeypatch.setattr(ops, "WINOGRAD_SQUARE", 0)   # the tall form itself; the square form has its own test below
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]))
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -239,6 +240,48 @@ def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
     e_s = (out_s.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     print(f"winograd42 split {case}: exact err {e_e / scale:.2e}, split err {e_s / scale:.2e}")
     assert e_s <= 2e-5 * scale and e_s <= 2 * e_e + 1e-6 * scale, (e_s, e_e, scale)
+
+
+@pytest.mark.parametrize("case", [(3, 4, 13, 512, 512, False, False), (2, 8, 25, 256, 256, True, True), (1, 17, 9, 128, 192, True, False),
+                                  (2, 12, 16, 160, 64, False, True), (1, 96, 128, 128, 128, True, False), (5, 16, 50, 128, 128, True, True)])
+def test_winograd44_square_form_vs_tall_and_f64(ops, case, monkeypatch):
+    """Round 4: F(4,3) x F(4,3) on the interpolation points {0, +-3/2, +-2/3, inf} (36 points per 4 x 4 outputs, 2.25 multiplies
+    and workspace words per output) against an f64 convolution: the 2e-5 bound of the tall form, and no more than 1.5x the tall
+    form's own error on the same layer (the point set was chosen for that: the textbook points {0, +-1, +-2} measure 4.7x) —
+    partial tiles on both axes, residual, ReLU, TRBA's 4 x 13 / 8 x 25 / 16 x 50 maps and an EAST-sized one."""
+    monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
+    N, H, W, Cin, Cout, relu, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 1)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xd, rd = _to_nhwc(x, torch.float32), (_to_nhwc(res, torch.float32) if use_res else None)
+    w_s = ops.attach_winograd(_w_khwc(w, torch.float32), True)
+    assert w_s._msocr_wino44_split.shape == (3, 36, Cin // 32, Cout, 32)
+    outs = {}
+    for square in (0, 1):
+        monkeypatch.setattr(ops, "WINOGRAD_SQUARE", square)
+        monkeypatch.setattr(ops, "_square_pays", lambda W_: True)
+        ops.PROFILE = []
+        big = torch.full((N, H, W, Cout + 32), 7.0, device="cuda")  # written into a channel slice
+        ops.conv2d(xd, w_s, b.cuda(), (1, 1), (1, 1), relu, rd, out=big[..., 32:])
+        tags = [t[4][3] for t in ops.PROFILE if t[2] == "conv_gemm"]
+        ops.PROFILE = None
+        assert tags == [("winograd44_split" if square else "winograd42_split")], tags
+        assert torch.all(big[..., :32] == 7.0)
+        plain = ops.conv2d(xd, w_s, b.cuda(), (1, 1), (1, 1), relu, rd)      # the one-call entry point (no profiling stages)
+        assert torch.equal(plain, big[..., 32:])
+        outs[square] = big[..., 32:].cpu().permute(0, 3, 1, 2).double()
+    scale = max(ref.abs().max().item(), 1.0)
+    e_t, e_q = (outs[0] - ref).abs().max().item(), (outs[1] - ref).abs().max().item()
+    print(f"winograd44 {case}: tall err {e_t / scale:.2e}, square err {e_q / scale:.2e}, ratio {e_q / e_t:.2f}")
+    assert e_q <= 2e-5 * scale and e_q <= 1.5 * e_t + 1e-6 * scale, (e_q, e_t, scale)
 
 
 FUSED64_CASES = [
