@@ -70,7 +70,7 @@ def parse():
 
 
 CONV_STAGE_KERNELS = ("conv_igemm_kernel", "conv_split_kernel", "conv_split_pp_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel",
-                      "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+                      "wino44_input_kernel", "wino44_output_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
 def _bf16_mfma_kernel(n):
@@ -549,8 +549,8 @@ def main():
         floor_s = pipe_seconds(gemm)
         peak = executed / floor_s / 1e12  # f32-equivalent TFLOP/s of this launch mix with every matrix pipe at its dense peak
         res["roofline"] = {
-            "kernel": "conv_split_pp_kernel + conv_split_kernel + conv_igemm_kernel (GEMM-shaped convolution work on the matrix cores: the 24-GEMM launch of every "
-                      "Winograd F(4,3)xF(2,3) layer and the 1x1 layers with f32 operands split exactly into three bf16 terms on "
+            "kernel": "conv_split_pp_kernel + conv_split_kernel + conv_igemm_kernel (GEMM-shaped convolution work on the matrix cores: the 36-GEMM launch of every "
+                      "Winograd F(4,3)xF(4,3) layer (24 for the tall F(4,3)xF(2,3) form of the Cin = 64 layers) and the 1x1 layers with f32 operands split exactly into three bf16 terms on "
                       "v_mfma_f32_16x16x32_bf16 / 32x32x16 (six products per f32 product, f32 accumulate); strided / 7x7 / 2x2 convolutions and the "
                       "LSTM / linear GEMMs on exact-f32 MFMA), over the convolution stage = those launches + the Winograd transform kernels",
             "bound": "mfma",
@@ -558,8 +558,8 @@ def main():
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": floor_s * 1e3 / stage_ms,
-            "definition": "achieved = f32-equivalent FLOP the GEMM launches execute (Winograd layers: 2*24*tiles*Cin*Cout per 4x2-output "
-                          "tile, 3x fewer than the direct form) / time in which at least one conv-stage kernel is executing (HIP events on "
+            "definition": "achieved = f32-equivalent FLOP the GEMM launches execute (Winograd layers: 2*36*tiles*Cin*Cout per 4x4-output "
+                          "tile, 4x fewer than the direct form; 2*24 per 4x2-output tile for the tall form) / time in which at least one conv-stage kernel is executing (HIP events on "
                           "the launch streams, sub-batch streams overlapping as in the timed region); peak = the same FLOP / the time the "
                           "launches need with the matrix pipe each one uses at its dense peak (split launches: 6 bf16 FLOP per f32-equivalent "
                           "FLOP at 2500 TFLOP/s = 416.7 f32-equivalent; exact-f32 launches: 157.3); frac = achieved / peak = matrix-pipe "
@@ -612,7 +612,7 @@ def main():
             "definition": "floor = GEMM launches at the dense peak of the matrix pipe each one uses (roofline.definition) + algorithmic bytes "
                           "of the Winograd transforms / 8 TB/s; frac = floor / conv-stage-busy time of the overlapped run, frac_isolated = "
                           "floor / summed isolated launch durations"}
-        names = {"wino_in": "wino42_input_kernel", "wino_out": "wino42_output_kernel", "se_residual": "se_residual_kernel",
+        names = {"wino_in": "wino44_input_kernel / wino42_input_kernel", "wino_out": "wino44_output_kernel / wino42_output_kernel", "se_residual": "se_residual_kernel",
                  "maxpool": "maxpool_kernel", "bilstm": "bilstm_kernel", "attn_beam": "attn_beam_mfma_kernel"}
         mean_run = (rec.last_run_length_sum / rec.last_rows) if (rec is not None and getattr(rec, "last_rows", 0)) else None
         sec = []

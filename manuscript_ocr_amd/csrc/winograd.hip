@@ -23,6 +23,33 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 1-D transforms of F(4,3) on the interpolation points {0, 3/2, -3/2, 2/3, -2/3, inf} (round 4; the matrices and why these points:
+// the comment block in front of wino44_input_kernel).  Used on both axes of the square form and on the H axis of the tall form.
+__device__ __forceinline__ void wino44_bt(const f32x4 d[6], f32x4 r[6]) {
+  constexpr float k97_36 = 97.0f / 36.0f, k4_9 = 4.0f / 9.0f, k9_4 = 2.25f, k3_2 = 1.5f, k2_3 = 2.0f / 3.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r[0][e] = fmaf(-k97_36, d[2][e], d[0][e]) + d[4][e];
+    r[5][e] = fmaf(-k97_36, d[3][e], d[1][e]) + d[5][e];
+    const float e1 = fmaf(-k4_9, d[2][e], d[4][e]), o1 = fmaf(k3_2, d[3][e], -k2_3 * d[1][e]);
+    const float e2 = fmaf(-k9_4, d[2][e], d[4][e]), o2 = fmaf(k2_3, d[3][e], -k3_2 * d[1][e]);
+    r[1][e] = e1 + o1; r[2][e] = e1 - o1;
+    r[3][e] = e2 + o2; r[4][e] = e2 - o2;
+  }
+}
+__device__ __forceinline__ void wino44_at(const f32x4 m[6], f32x4 y[4]) {
+  constexpr float k3_2 = 1.5f, k2_3 = 2.0f / 3.0f, k9_4 = 2.25f, k4_9 = 4.0f / 9.0f, k27_8 = 3.375f, k8_27 = 8.0f / 27.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float p12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], p34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+    y[0][e] = (m[0][e] + p12) + p34;
+    y[1][e] = fmaf(k3_2, d12, k2_3 * d34);
+    y[2][e] = fmaf(k9_4, p12, k4_9 * p34);
+    y[3][e] = fmaf(k27_8, d12, k8_27 * d34) + m[5][e];
+  }
+}
+
+
 struct WinoGeom {
   int N, H, W;      // image extent (output extent is the same: stride 1, pad 1)
   int TH, TW;       // 2x2-output tiles per image
@@ -202,9 +229,11 @@ extern "C" int msocr_conv3x3_winograd(const msocr_conv_desc* d, const void* in, 
 // =====================================================================================================================
 // The TALL form: F(4,3) along H x F(2,3) along W.  A 6x4 input tile gives a 4x2 output tile through 24 transform-domain
 // products: 3 multiplies per output instead of 4 (direct: 9), V / Mw expanded 3x instead of 4x.  Only the H axis takes the
-// 6-point transform: its constants (4, 5, 2, 8; 1/6, 1/24 in the weights) grow the f32 rounding error of the layer by ~2.5x rms
-// over F(2x2) (measured against f64: DESIGN.md section 4), where the 6x6 form would grow it 6x.  ops.conv2d() picks this form
-// when 24 * ceil(H/4) < 16 * ceil(H/2) (H = 4, 7, 8, >= 11 ...: every map of the pipeline), the 2x2 form otherwise.
+// 6-point transform: on the textbook points {0, +-1, +-2, inf} its constants (4, 5, 2, 8; 1/6, 1/24 in the weights) grew the f32
+// rounding error of the layer by ~2.5x rms over F(2x2) (measured against f64: DESIGN.md section 4), where the 6x6 form would grow
+// it 6x.  Since round 4 the H axis runs on the points {0, +-3/2, +-2/3, inf} (wino44_bt / wino44_at above): half that error, and
+// the 6x6 form on them (wino44_*, below) comes out where this form used to be.  ops.conv2d() picks the tall form for the Cin = 64
+// layers (fused kernels) and where the square form does not pay; the 2x2 form when 24 * ceil(H/4) >= 16 * ceil(H/2).
 //   V[(xi*4+nu)][tile][c], xi = 0..5 (H axis), nu = 0..3 (W axis); Mw likewise; U from msocr_winograd42_weights_host.
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void wino42_input_kernel(const float* __restrict__ in, long sN, long sH, long sW, int C,
@@ -243,14 +272,11 @@ __global__ __launch_bounds__(256) void wino42_input_kernel(const float* __restri
   float* o = V + t * (long)C + c;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const f32x4 a0 = q[0][j], a1 = q[1][j], a2 = q[2][j], a3 = q[3][j], a4 = q[4][j], a5 = q[5][j];
-    const f32x4 e42 = a4 - a2, e31 = a3 - a1;
-    *reinterpret_cast<f32x4*>(o + (0 * 4 + j) * plane) = (4.f * a0 - 5.f * a2) + a4;
-    *reinterpret_cast<f32x4*>(o + (1 * 4 + j) * plane) = (a3 + a4) - 4.f * (a1 + a2);
-    *reinterpret_cast<f32x4*>(o + (2 * 4 + j) * plane) = (a4 - a3) + 4.f * (a1 - a2);
-    *reinterpret_cast<f32x4*>(o + (3 * 4 + j) * plane) = e42 + 2.f * e31;
-    *reinterpret_cast<f32x4*>(o + (4 * 4 + j) * plane) = e42 - 2.f * e31;
-    *reinterpret_cast<f32x4*>(o + (5 * 4 + j) * plane) = (4.f * a1 - 5.f * a3) + a5;
+    const f32x4 col[6] = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j]};
+    f32x4 v[6];
+    wino44_bt(col, v);   // H axis on the accuracy-chosen points (round 4: half the rounding error of {0, +-1, +-2})
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(o + (i * 4 + j) * plane) = v[i];
   }
 }
 
@@ -275,11 +301,9 @@ __global__ __launch_bounds__(256) void wino42_output_kernel(const float* __restr
     f32x4 m[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + (i * 4 + j) * plane);
-    const f32x4 p12 = m[1] + m[2], d12 = m[1] - m[2], p34 = m[3] + m[4], d34 = m[3] - m[4];
-    s[0][j] = (m[0] + p12) + p34;
-    s[1][j] = d12 + 2.f * d34;
-    s[2][j] = p12 + 4.f * p34;
-    s[3][j] = (d12 + 8.f * d34) + m[5];
+    f32x4 y6[4];
+    wino44_at(m, y6);
+    s[0][j] = y6[0]; s[1][j] = y6[1]; s[2][j] = y6[2]; s[3][j] = y6[3];
   }
   f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (bias) b = *reinterpret_cast<const f32x4*>(bias + c);
@@ -405,30 +429,6 @@ extern "C" int msocr_conv3x3_winograd42_split(const msocr_conv_desc* d, const vo
 //   V[(xi*6+nu)][tile][c], xi = 0..5 (H axis), nu = 0..5 (W axis); Mw likewise; U from msocr_winograd44_weights_host.
 // Reference layers: the 3x3 / stride 1 / pad 1 convolutions of seresnet31.py:37-67 and of torchvision's Bottleneck (east.py:13-30).
 // =====================================================================================================================
-__device__ __forceinline__ void wino44_bt(const f32x4 d[6], f32x4 r[6]) {
-  constexpr float k97_36 = 97.0f / 36.0f, k4_9 = 4.0f / 9.0f, k9_4 = 2.25f, k3_2 = 1.5f, k2_3 = 2.0f / 3.0f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    r[0][e] = fmaf(-k97_36, d[2][e], d[0][e]) + d[4][e];
-    r[5][e] = fmaf(-k97_36, d[3][e], d[1][e]) + d[5][e];
-    const float e1 = fmaf(-k4_9, d[2][e], d[4][e]), o1 = fmaf(k3_2, d[3][e], -k2_3 * d[1][e]);
-    const float e2 = fmaf(-k9_4, d[2][e], d[4][e]), o2 = fmaf(k2_3, d[3][e], -k3_2 * d[1][e]);
-    r[1][e] = e1 + o1; r[2][e] = e1 - o1;
-    r[3][e] = e2 + o2; r[4][e] = e2 - o2;
-  }
-}
-__device__ __forceinline__ void wino44_at(const f32x4 m[6], f32x4 y[4]) {
-  constexpr float k3_2 = 1.5f, k2_3 = 2.0f / 3.0f, k9_4 = 2.25f, k4_9 = 4.0f / 9.0f, k27_8 = 3.375f, k8_27 = 8.0f / 27.0f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float p12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], p34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-    y[0][e] = (m[0][e] + p12) + p34;
-    y[1][e] = fmaf(k3_2, d12, k2_3 * d34);
-    y[2][e] = fmaf(k9_4, p12, k4_9 * p34);
-    y[3][e] = fmaf(k27_8, d12, k8_27 * d34) + m[5][e];
-  }
-}
-
 __global__ __launch_bounds__(256) void wino44_input_kernel(const float* __restrict__ in, long sN, long sH, long sW, int C,
                                                             WinoGeom g, float* __restrict__ V) {
   const int cch = C >> 2;
@@ -823,11 +823,11 @@ __global__ __launch_bounds__(256, 3) void wino42_fused64_kernel(const float* __r
     for (int j = 0; j < 4; ++j) {
       const float m0_ = acc[0 * 4 + j][e], m1 = acc[1 * 4 + j][e], m2 = acc[2 * 4 + j][e], m3 = acc[3 * 4 + j][e], m4 = acc[4 * 4 + j][e],
                   m5 = acc[5 * 4 + j][e];
-      const float p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
+      const float p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;   // A^T of wino44_at, scalar
       s[0][j] = (m0_ + p12) + p34;
-      s[1][j] = d12 + 2.f * d34;
-      s[2][j] = p12 + 4.f * p34;
-      s[3][j] = (d12 + 8.f * d34) + m5;
+      s[1][j] = fmaf(1.5f, d12, (2.0f / 3.0f) * d34);
+      s[2][j] = fmaf(2.25f, p12, (4.0f / 9.0f) * p34);
+      s[3][j] = fmaf(3.375f, d12, (8.0f / 27.0f) * d34) + m5;
     }
     float y[4][2];
 #pragma unroll
@@ -950,13 +950,14 @@ __global__ __launch_bounds__(256, 2) void wino42_fused64_v2_kernel(const float* 
   gload(0);
   sstore();
   __syncthreads();
-  // coefficient of point p = 4 i + j in output o = 2 a + b: AT6[a][i] * AT4[b][j], AT6 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],
-  // [0,1,-1,8,-8,1]], AT4 = [[1,1,1,0],[0,1,-1,-1]] — a run-time table and a ROLLED loop over the points: unrolled, the 24 points'
+  // coefficient of point p = 4 i + j in output o = 2 a + b: AT6[a][i] * AT4[b][j], AT6 = A^T of wino44_at (the points
+  // {0, +-3/2, +-2/3, inf} since round 4), AT4 = [[1,1,1,0],[0,1,-1,-1]] — a run-time table and a ROLLED loop over the points: unrolled, the 24 points'
   // loads and products are hoisted across each other and the kernel spills (375 registers fully unrolled, 128 with four points
   // per iteration); the price is 8 FMAs per element and point including the 84 zero coefficients (192 instead of 108)
   __shared__ float s_cf[24][8];
   if (tid < 192) {
-    const float t6[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    const float t6[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1.5f, -1.5f, 2.0f / 3.0f, -2.0f / 3.0f, 0}, {0, 2.25f, 2.25f, 4.0f / 9.0f, 4.0f / 9.0f, 0},
+                            {0, 3.375f, -3.375f, 8.0f / 27.0f, -8.0f / 27.0f, 1}};   // A^T on the points {0, +-3/2, +-2/3, inf}
     const float t4[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
     const int pp = tid >> 3, o = tid & 7;
     s_cf[pp][o] = t6[o >> 1][pp >> 2] * t4[o & 1][pp & 3];
@@ -1136,8 +1137,11 @@ extern "C" int msocr_conv3x3_winograd42_fused_split(const msocr_conv_desc* d, co
 // HOST function like msocr_winograd_weights_host.
 extern "C" int msocr_winograd42_weights_host(const float* w_khwc, int Cout, int Cin, float* u_out) {
   if (!w_khwc || !u_out || Cout <= 0 || Cin <= 0) return MSOCR_E_ARG;
-  static const double G6[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  // H axis: the points {0, 3/2, -3/2, 2/3, -2/3, inf} (round 4), as msocr_winograd44_weights_host
+  static const double G6[6][3] = {{1.0, 0.0, 0.0},
+                                  {8.0 / 65, 12.0 / 65, 18.0 / 65},     {8.0 / 65, -12.0 / 65, 18.0 / 65},
+                                  {-81.0 / 130, -27.0 / 65, -18.0 / 65}, {-81.0 / 130, 27.0 / 65, -18.0 / 65},
+                                  {0.0, 0.0, 1.0}};
   static const double G4[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
   const long plane = (long)Cout * Cin;
   for (int co = 0; co < Cout; ++co) {

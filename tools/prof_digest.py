@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_STAGE = ("conv_split_kernel", "conv_split_pp_kernel", "conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
+CONV_STAGE = ("conv_split_kernel", "conv_split_pp_kernel", "conv_igemm_kernel", "wino_input_kernel", "wino_output_kernel", "wino42_input_kernel", "wino42_output_kernel", "wino44_input_kernel", "wino44_output_kernel", "wino42_fused64_kernel", "wino42_fused64_v2_kernel", "wino_gemm4_kernel", "wino_rows_in_kernel", "wino_rows_out_kernel")
 
 
 def one(pattern):
