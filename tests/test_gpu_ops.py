@@ -246,9 +246,11 @@ def test_winograd42_split_vs_exact_and_f64(ops, case, monkeypatch):
                                   (2, 12, 16, 160, 64, False, True), (1, 96, 128, 128, 128, True, False), (5, 16, 50, 128, 128, True, True)])
 def test_winograd44_square_form_vs_tall_and_f64(ops, case, monkeypatch):
     """Round 4: F(4,3) x F(4,3) on the interpolation points {0, +-3/2, +-2/3, inf} (36 points per 4 x 4 outputs, 2.25 multiplies
-    and workspace words per output) against an f64 convolution: the 2e-5 bound of the tall form, and no more than 1.5x the tall
-    form's own error on the same layer (the point set was chosen for that: the textbook points {0, +-1, +-2} measure 4.7x) —
-    partial tiles on both axes, residual, ReLU, TRBA's 4 x 13 / 8 x 25 / 16 x 50 maps and an EAST-sized one."""
+    and workspace words per output) against an f64 convolution: the 2e-5 bound of the tall form, and no more than 3x the tall
+    form's own error on the same layer — the tall form runs its H axis on the same points since round 4, which halved ITS error;
+    against the tall form on the textbook points {0, +-1, +-2} (rounds 2-3) the square form measures 1.1-1.3x, and on those points
+    itself 4.7x (tools/winograd_points.py) — partial tiles on both axes, residual, ReLU, TRBA's 4 x 13 / 8 x 25 / 16 x 50 maps and an
+    EAST-sized one."""
     monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]) + 1)
@@ -281,7 +283,7 @@ def test_winograd44_square_form_vs_tall_and_f64(ops, case, monkeypatch):
     scale = max(ref.abs().max().item(), 1.0)
     e_t, e_q = (outs[0] - ref).abs().max().item(), (outs[1] - ref).abs().max().item()
     print(f"winograd44 {case}: tall err {e_t / scale:.2e}, square err {e_q / scale:.2e}, ratio {e_q / e_t:.2f}")
-    assert e_q <= 2e-5 * scale and e_q <= 1.5 * e_t + 1e-6 * scale, (e_q, e_t, scale)
+    assert e_q <= 2e-5 * scale and e_q <= 3.0 * e_t + 1e-7 * scale, (e_q, e_t, scale)
 
 
 FUSED64_CASES = [
@@ -363,13 +365,25 @@ def test_winograd_weight_transform_matches_definition(ops):
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
     exp = torch.einsum("xk,ockl,nl->xnoc", G, w.double(), G).reshape(16, 64, 128).float()
     assert torch.equal(wk._msocr_wino.cpu(), exp)
-    G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                       [0, 0, 1]], dtype=torch.float64)
+    # F(4,3) on the points {0, 3/2, -3/2, 2/3, -2/3, inf} (round 4): G[j] = [1, a, a^2] / prod_{l != j}(a_j - a_l), last row [0, 0, 1]
+    pts = [0.0, 1.5, -1.5, 2 / 3, -2 / 3]
+    G6 = torch.zeros(6, 3, dtype=torch.float64)
+    for j, a in enumerate(pts):
+        f = np.prod([a - b for l, b in enumerate(pts) if l != j])
+        G6[j] = torch.tensor([1.0, a, a * a], dtype=torch.float64) / f
+    G6[5, 2] = 1.0
     exp42 = torch.einsum("xk,ockl,nl->xnoc", G6, w.double(), G).reshape(24, 64, 128)
     got42 = wk._msocr_wino42.cpu()
     assert got42.shape == (24, 64, 128)
     # f64 evaluation in a different summation order than einsum's: equal after the single rounding to f32 up to 1 ulp
     assert (got42.double() - exp42).abs().max().item() <= 1.2e-7 * exp42.abs().max().item()
+    u44 = torch.empty((36, 64, 128), dtype=torch.float32)
+    wh = _w_khwc(w, torch.float32).cpu().contiguous()
+    from manuscript_ocr_amd import _native as nat
+    nat.check(nat.lib().msocr_winograd44_weights_host(wh.data_ptr(), 64, 128, u44.data_ptr()), "winograd44_weights_host")
+    exp44 = torch.einsum("xk,ockl,nl->xnoc", G6, w.double(), G6).reshape(36, 64, 128)
+    assert (u44.double() - exp44).abs().max().item() <= 1.2e-7 * exp44.abs().max().item()
+    assert torch.equal(ops.unsplit_planes_ktile(wk._msocr_wino44_split.cpu()), u44)   # the planes the kernels read: the exact three-term split
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
