@@ -156,6 +156,9 @@ def test_trba_predict_matches_oracle_text_and_confidence(env, mode):
     np.testing.assert_allclose([got[i]["confidence"] for i in same], [exp[i]["confidence"] for i in same], atol=1e-4)
 
 
+_ORACLE_DECODES = {}   # (seed, N, mode, max_len) -> (oracle net, rows, batch_H): the CPU decode of one case is the same for every device variant
+
+
 def _random_weight_case(otm, seed, N, mode, rec, canv=None, max_len=25):
     """GPU decode (ids, run lengths, logits, confidences), the oracle's rows for N synthetic crops (all-random weights), and the
     CALIBRATED logit bounds of that case (oracle/decode_check.py::calibrated_logit_bounds): the device's encoder output is
@@ -163,13 +166,19 @@ def _random_weight_case(otm, seed, N, mode, rec, canv=None, max_len=25):
     of that size — the device's logit-error distribution has to lie within 2x the oracle's own response."""
     from conftest import calibrated_logit_bounds, oracle_decode_chunks
     sd = synth.trba_state_dict(194, 256, seed=seed)
+    key = (seed, N, mode, max_len) if canv is None else None
     if canv is None:
         canv = synth.synth_crops(seed % 1000 + 5, N, 32, 100)
-    ref_net = otm.TRBANet(194, 256)
-    ref_net.load_state_dict(sd, strict=True)
-    ref_net.eval()
-    keep = []
-    exp = oracle_decode_chunks(ref_net, _x_from_canvases(canv), mode, max_len=max_len, keep_batch_H=keep)
+    if key in _ORACLE_DECODES:
+        ref_net, exp, keep = _ORACLE_DECODES[key]
+    else:
+        ref_net = otm.TRBANet(194, 256)
+        ref_net.load_state_dict(sd, strict=True)
+        ref_net.eval()
+        keep = []
+        exp = oracle_decode_chunks(ref_net, _x_from_canvases(canv), mode, max_len=max_len, keep_batch_H=keep)
+        if key is not None:
+            _ORACLE_DECODES[key] = (ref_net, exp, keep)
     canv_dev = torch.from_numpy(canv).cuda()
     dev_bH = rec.model.encode(canv_dev)[0].float().cpu().numpy()
     cal = calibrated_logit_bounds(ref_net, np.concatenate(keep), dev_bH, exp, mode, max_len=max_len)
