@@ -12,6 +12,8 @@ in libmsocr.so.  Mirrors the reference forward
 State-dict keys are the reference's (`backbone.extractor.*`, `decoder.block*`,
 `output_head.*`), loaded non-strictly like east.py:130-133.
 """
+import os
+
 import torch
 
 from ... import ops
@@ -102,10 +104,18 @@ def fold_bn(w, conv_bias, prefix_bn, sd):
     return w2, b2
 
 
-def to_khwc(w, dtype, device, split=None):
-    """OIHW -> [Cout][KH][KW][Cin] on the device; 3x3 f32 weights also get their Winograd twin (ops.attach_winograd), f32 1x1 weights
-    and the tall-Winograd U their three bf16 planes (ops.attach_split; split=False keeps a layer on the exact-f32 MFMA)."""
-    return ops.attach_split(ops.attach_winograd(w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), split), split)
+def to_khwc(w, dtype, device, split=None, square=True):
+    """OIHW -> [Cout][KH][KW][Cin] on the device; 3x3 f32 weights also get their Winograd twins (ops.attach_winograd; square=False:
+    no F(4,3) x F(4,3) twin, the layer stays on the tall form), f32 1x1 weights and the Winograd U their three bf16 planes
+    (ops.attach_split; split=False keeps a layer on the exact-f32 MFMA)."""
+    return ops.attach_split(ops.attach_winograd(w.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), split, square), split)
+
+
+# The detector's 3x3 layers stay on the TALL Winograd form: the geometry map carries the tightest tolerance of the path (BASELINE.md:
+# 1e-4 absolute on offsets of up to tens of pixels), the tall form on the round-4 interpolation points has half the rounding error
+# of anything before it, and these layers are 4 ms of a 183 ms step (the square form would save 2.5 ms and spend the margin:
+# f64 arbitration of the geometry 1.84 of the allowed 2.0 with it).  MSOCR_EAST_WINO_SQUARE=1 switches them over.
+EAST_WINO_SQUARE = os.environ.get("MSOCR_EAST_WINO_SQUARE", "0") != "0"
 
 
 def pack_stem_weight(w, cin_pad, cpad=4):
@@ -145,10 +155,10 @@ class EastNet:
                 p = f"{bb}{lname}.{i}."
                 for j in (1, 2, 3):
                     w, b = conv_bn(p + f"conv{j}", p + f"bn{j}")
-                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
+                    P[f"{lname}.{i}.conv{j}"] = (to_khwc(w, dtype, self.device, split, EAST_WINO_SQUARE), b.to(self.device))
                 if i == 0:
                     wd, bd = conv_bn(p + "downsample.0", p + "downsample.1")
-                    P[f"{lname}.{i}.down"] = (to_khwc(wd, dtype, self.device, split), bd.to(self.device))
+                    P[f"{lname}.{i}.down"] = (to_khwc(wd, dtype, self.device, split, EAST_WINO_SQUARE), bd.to(self.device))
                     if stride == 1:
                         # conv3 and the stride-1 downsample of the layer's first block read the same pixels: one GEMM over the
                         # channel concatenation [conv2 output | block input] with [W3 | Wd] (K = planes + Cin) replaces two
@@ -158,9 +168,9 @@ class EastNet:
         for k in (1, 2, 3, 4):
             p = f"decoder.block{k}."
             w, b = conv_bn(p + "conv1x1.0", p + "conv1x1.1", p + "conv1x1.0.bias")
-            P[f"dec{k}.a"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
+            P[f"dec{k}.a"] = (to_khwc(w, dtype, self.device, split, EAST_WINO_SQUARE), b.to(self.device))
             w, b = conv_bn(p + "conv3x3.0", p + "conv3x3.1", p + "conv3x3.0.bias")
-            P[f"dec{k}.b"] = (to_khwc(w, dtype, self.device, split), b.to(self.device))
+            P[f"dec{k}.b"] = (to_khwc(w, dtype, self.device, split, EAST_WINO_SQUARE), b.to(self.device))
         w9 = torch.cat([sd["output_head.score_map.weight"].float().view(1, 32), sd["output_head.geo_map.weight"].float().view(8, 32)])
         b9 = torch.cat([sd["output_head.score_map.bias"].float().view(1), sd["output_head.geo_map.bias"].float().view(8)])
         self.w9, self.b9 = w9.contiguous().to(self.device), b9.contiguous().to(self.device)

@@ -176,7 +176,7 @@ def attach_split(w, split=None):
     return w
 
 
-def attach_winograd(w, split=None):
+def attach_winograd(w, split=None, square=True):
     """Load-time: give a [Cout,3,3,Cin] f32 device weight its transform-domain twins U = G g G^T ([16,Cout,Cin] f32 for F(2x2,3x3),
     [24,Cout,Cin] for the tall form F(4,3) x F(2,3); computed on the host in f64 by msocr_winograd[42]_weights_host).  conv2d() then
     takes the Winograd path for 3x3/1/1 calls."""
@@ -205,7 +205,7 @@ def attach_winograd(w, split=None):
     w._msocr_wino42 = u42.to(w.device)
     if (SPLIT_BF16X3 if split is None else split) and Cin % 32 == 0 and Cout % 64 == 0:
         w._msocr_wino42_split = split_planes_ktile(u42, 24, Cout).to(w.device)  # [3][24][Cin/32][Cout][32] bf16
-        if WINOGRAD_SQUARE:
+        if WINOGRAD_SQUARE and square:  # square=False: the caller keeps this layer on the tall form (half the rounding error)
             u44 = torch.empty((36, Cout, Cin), dtype=torch.float32)
             nat.check(nat.lib().msocr_winograd44_weights_host(wh.data_ptr(), Cout, Cin, u44.data_ptr()), "winograd44_weights_host")
             w._msocr_wino44_split = split_planes_ktile(u44, 36, Cout).to(w.device)  # [3][36][Cin/32][Cout][32] bf16
