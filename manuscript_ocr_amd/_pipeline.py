@@ -219,7 +219,7 @@ class Pipeline:
             return tuple(read_image(im).shape[:2])
 
     def submit_batch(self, images, recognize_text: bool = True, profile: bool = False, pages_dev=None, sub_batches: int = 0,
-                     _maps_override=None):
+                     _maps_override=None, _device_entropy=None):
         """Stage 1 of `predict_batch`: upload (if needed) and enqueue every group's detector work; returns a handle
         without synchronising.  Consecutive submits alternate between two sets of streams, so the detector work of
         batch i+1 can be enqueued before `collect_batch` of batch i and fills the device while batch i drains."""
@@ -231,10 +231,12 @@ class Pipeline:
         # image ingest: a JPEG file is decoded ON THE DEVICE (host Huffman stage + HIP reconstruction, ingest.py) — the page's
         # pixels never exist on the host, `arrays` then only carries the shape; everything else goes through read_image
         arrays, decoded = [], []
-        dec = [None] * len(images)
+        dec, ingest_pending = [None] * len(images), None
         if pages_dev is None and getattr(self, "device_ingest", True):
             from . import ingest
-            dec = ingest.read_images_device(list(images), det.device)  # host Huffman stages of the batch in parallel
+            # Huffman stage on the device for files with restart intervals, on a host thread pool otherwise; the device stage's
+            # verdict on corrupt streams is read in advance_batch (ingest.check_pending), not here
+            dec, ingest_pending = ingest.read_images_device(list(images), det.device, device_entropy=_device_entropy, defer_status=True)
         for im, t in zip(images, dec):
             if t is not None:
                 arrays.append(np.broadcast_to(np.uint8(0), tuple(t.shape)))
@@ -307,7 +309,9 @@ class Pipeline:
                 ev.record(st)  # detector outputs of this group complete
                 det_events.append(ev)
         return {"arrays": arrays, "pages_dev": pages_dev, "bounds": bounds, "streams": streams, "det_streams": det_streams, "main": main,
-                "det_handles": det_handles, "ro_handles": ro_handles, "det_events": det_events, "recognize_text": recognize_text, "profile": profile}
+                "det_handles": det_handles, "ro_handles": ro_handles, "det_events": det_events, "recognize_text": recognize_text, "profile": profile,
+                "ingest_pending": ingest_pending,
+                "resubmit": (lambda: self.submit_batch(images, recognize_text, profile, None, sub_batches, _maps_override, _device_entropy=False))}
 
     def advance_batch(self, h):
         """Stage 2 of `predict_batch` for a handle from `submit_batch`: per group — wait for its boxes, run the host
@@ -318,7 +322,16 @@ class Pipeline:
             return h
         import torch
 
-        from . import ops
+        from . import ingest, ops
+        if h.get("ingest_pending") is not None:
+            # the device Huffman stage's verdict on this batch's files (queued right behind the kernels, long done by now): a corrupt
+            # stream gets what the host decoder's verdict gives it — the whole batch is read again through the host path (rare)
+            bad = ingest.check_pending(h["ingest_pending"])
+            h["ingest_pending"] = None
+            if bad:
+                h2 = h["resubmit"]()
+                h.clear()
+                h.update(h2)
         det, rec = self.detector, self.recognizer
         arrays, pages_dev, bounds, streams = h["arrays"], h["pages_dev"], h["bounds"], h["streams"]
         recognize_text, profile = h["recognize_text"], h["profile"]

@@ -201,7 +201,18 @@ def _load(path, arr, off, n, want_device):
     return info, (_prepare(ptr, n, info, off) if want_device else None)
 
 
-def read_images_device(paths, device="cuda", device_entropy=None):
+def check_pending(pending):
+    """Deferred verdict of the device Huffman stage (`read_images_device(..., defer_status=True)`): waits for the status words of
+    that batch (a copy that was queued right behind the kernels; by the time a caller asks, long done) -> indices of the pages whose
+    stream the kernel flagged as bad (they must be read again through the host path)."""
+    if pending is None:
+        return []
+    st_host, ev, idx = pending
+    ev.synchronize()
+    return [i for i, s in zip(idx, st_host.tolist()) if s != 0]
+
+
+def read_images_device(paths, device="cuda", device_entropy=None, defer_status=False):
     """A batch of files -> list of device RGB tensors (None where read_image must take over).
     A thread pool reads every file into its slice of ONE pinned batch buffer (reused across batches), parses its headers and walks
     its markers (the ctypes calls release the GIL).  Files with a restart interval: the buffer is uploaded as it is and the Huffman
@@ -211,7 +222,11 @@ def read_images_device(paths, device="cuda", device_entropy=None):
     host core; `device_entropy=True` / False or MSOCR_JPEG_DEVICE_ENTROPY=1 / 0 force one path).
     Files without: the entropy decode is one serial bit stream per FILE, but files are independent: the pool decodes one page per
     core into per-slot PINNED coefficient buffers that live across batches (fresh 9 MB arrays per page made the threads serialise
-    on page faults), this thread uploads and launches the reconstruction page by page as the decodes finish."""
+    on page faults), this thread uploads and launches the reconstruction page by page as the decodes finish.
+    defer_status=True -> (list, pending): the device path's one host wait — the kernel's per-page verdict — is NOT taken here; the
+    caller asks `check_pending(pending)` later (the pipeline does, when it waits for the detector anyway).  Waiting here puts the
+    ingest kernels' queueing delay behind a chip full of recogniser work on the host's critical path (measured: 41 instead of 83
+    pages/s from files on a box where it hit)."""
     global _POOL
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -230,8 +245,9 @@ def read_images_device(paths, device="cuda", device_entropy=None):
     for n in sizes:
         offs.append(total)
         total += (max(n, 0) + 15) // 16 * 16
+    pending = None
     if total == 0:
-        return [None] * len(paths)
+        return ([None] * len(paths), None) if defer_status else [None] * len(paths)
     ent = _slot_buffer("bytes", total, torch, torch.uint8)
     arr = ent[0].numpy()
     want = device_entropy is not False
@@ -250,8 +266,17 @@ def read_images_device(paths, device="cuda", device_entropy=None):
             ent[1].record()
             coef, status = entropy_batch_device(batch, device, bytes_dev)
             imgs = [_reconstruct(info, coef[base:], device, torch, ops) for info, base in batch.infos]
-            bad = status.cpu().numpy()   # the one wait of this path: a bad stream must go to the host reader, as the host decoder's verdict would
-            on_dev = {i: (imgs[k] if bad[k] == 0 else None) for i, k in enumerate(batch.pages) if k >= 0}
+            idx = [i for i, k in enumerate(batch.pages) if k >= 0]
+            if defer_status:
+                st_host = torch.empty(batch.n_pages, dtype=torch.int32).pin_memory()
+                st_host.copy_(status, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending = (st_host, ev, idx)
+                on_dev = {i: imgs[batch.pages[i]] for i in idx}
+            else:
+                bad = status.cpu().numpy()   # the one wait of this path: a bad stream must go to the host reader, as the host decoder's verdict would
+                on_dev = {i: (imgs[batch.pages[i]] if bad[batch.pages[i]] == 0 else None) for i in idx}
     lib = nat.lib()
     futs = []
     for i, r in enumerate(loaded):
@@ -273,7 +298,7 @@ def read_images_device(paths, device="cuda", device_entropy=None):
         slot[1] = torch.cuda.Event()
         slot[1].record()
         out.append(_reconstruct(info, coef_dev, device, torch, ops))
-    return out
+    return (out, pending) if defer_status else out
 
 
 def read_image_device(path, device="cuda"):

@@ -487,6 +487,33 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
         verdicts.add(ref is None)
         assert np.array_equal(r[0].cpu().numpy(), got[0].cpu().numpy()) and np.array_equal(r[2].cpu().numpy(), got[2].cpu().numpy())
     assert verdicts == {True, False}
+    # ... and through the plugin API, where the kernel's verdict is read late (advance_batch): a file the kernel flags is read again
+    # by the host reader (PIL / cv2 tolerate what libjpeg tolerates), the result equals predicting on that reader's array
+    from manuscript_ocr_amd import Pipeline
+    from manuscript_ocr_amd.detectors import EAST
+    from manuscript_ocr_amd.recognizers import TRBA
+    from manuscript_ocr_amd.detectors._east.utils import read_image
+    flagged = None
+    for trial in range(200):
+        t = bytearray(bad)
+        t[int(rng.integers(sos + 14, len(t) - 2))] = int(rng.integers(0, 255))
+        if ingest.decode_jpeg_host(bytes(t)) is None:
+            (tmp_path / "flagged.jpg").write_bytes(bytes(t))
+            try:
+                arr = read_image(str(tmp_path / "flagged.jpg"))
+            except Exception:
+                continue
+            flagged = arr
+            break
+    assert flagged is not None
+    cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), target_size=(320, 208), device="cuda", score_thresh=0.5),
+                    TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda"))
+    key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
+    good = np.array(Image.open(files[2]).convert("RGB"))
+    a = pipe.predict_batch([files[2], str(tmp_path / "flagged.jpg")])
+    b = pipe.predict_batch([good, flagged])
+    assert [key(p) for p in a] == [key(p) for p in b]
     # (d) bench-sized pages: 4 x 2048 x 1536, one interval per MCU row (12 KB intervals: the default policy sends them to the host
     #     decoder, device_entropy=True to the kernel — spread one interval per wave) and 16-MCU intervals (the kernel by default)
     pages = [synth.synth_page(70 + k, 2048, 1536)[0] for k in range(4)]
