@@ -507,7 +507,7 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
             break
     assert flagged is not None
     cfg = {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
-    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), target_size=(320, 208), device="cuda", score_thresh=0.5),
+    pipe = Pipeline(EAST(state_dict=synth.east_state_dict(), target_size=(320, 224), device="cuda", score_thresh=0.5),
                     TRBA(state_dict=synth.trba_state_dict_confident(194, 256, seed=3), config=cfg, device="cuda"))
     key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
     good = np.array(Image.open(files[2]).convert("RGB"))
