@@ -469,10 +469,13 @@ def main():
                     _Image.fromarray(pg_).save(paths[-1], quality=90)
                     paths_dri.append(os.path.join(td, f"r{i_}.jpg"))
                     _Image.fromarray(pg_).save(paths_dri[-1], quality=90, restart_marker_blocks=16)
-                pages, a.host_pages = paths_dri, True     # file bytes -> device Huffman stage (one thread per restart interval) -> device reconstruction
+                pages, a.host_pages = paths, True         # files without restart markers: entropy decode on a host thread pool (ingest.py)
                 sec["jpeg_ingest"] = secondary_rate()
-                pages = paths                             # no restart markers: entropy decode on a host thread pool (ingest.py)
-                sec["jpeg_ingest_host_entropy"] = secondary_rate()
+                pages = paths_dri                         # restart interval 16 MCUs: the batch pipeline's default is still the host pool ...
+                sec["jpeg_ingest_restart_intervals"] = secondary_rate()
+                pipe.device_entropy = True                # ... and this forces the device Huffman stage (one thread per restart interval)
+                sec["jpeg_ingest_device_entropy"] = secondary_rate()
+                pipe.device_entropy = None
                 sec["jpeg_bytes_per_page"] = int(sum(os.path.getsize(p_) for p_ in paths_dri) / len(paths_dri))
         except Exception as e_:  # a secondary line must never take the headline down
             sec["error"] = repr(e_)[:300]
@@ -480,9 +483,10 @@ def main():
             pipe, pages, a.host_pages = keep
         sec["note"] = ("pages/s of the same loop, 3 steps each after the timed region: host_pages = pages handed over as host arrays "
                        "(PCIe-inclusive), graphs = EAST/TRBA(use_graphs=True), jpeg_ingest = pages read from JPEG files (quality 90, "
-                       "4:2:0, restart interval 16 MCUs) through ingest.py: Huffman stage AND reconstruction on the device; "
-                       "jpeg_ingest_host_entropy = the same pages written without restart markers: entropy decode on a host thread "
-                       "pool, reconstruction on the device")
+                       "4:2:0) through ingest.py: entropy decode on a host thread pool, reconstruction on the device; "
+                       "jpeg_ingest_restart_intervals = the same pages written with a restart interval of 16 MCUs (same path by default); "
+                       "jpeg_ingest_device_entropy = those files with the Huffman stage forced onto the device (one thread per interval): "
+                       "faster on an idle chip, erratic inside the saturated pipeline (DESIGN.md section 7)")
         res["secondary_lines"] = sec
     if pipe is not None:
         res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}

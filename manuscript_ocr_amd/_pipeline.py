@@ -11,6 +11,7 @@ recogniser once for all crops of all pages (results identical to per-page predic
 """
 import contextlib
 import gc
+import os
 import time
 from typing import List, Optional, Union
 
@@ -232,18 +233,17 @@ class Pipeline:
         # pixels never exist on the host, `arrays` then only carries the shape; everything else goes through read_image
         arrays, decoded = [], []
         dec, ingest_pending = [None] * len(images), None
-        # Ingest work (Huffman kernel, reconstruction, uploads) runs on its own HIGH-priority stream: the next batch's detector waits
-        # for it, and at normal priority its few long-latency workgroups queue behind a chip full of recogniser GEMMs (persistent
-        # workgroups that hold every SIMD's registers) — measured from files: 70 pages/s on the default stream against 79 for the host
-        # entropy path.  The launch stream then waits for it on the device; nothing waits on the host.
-        cur = torch.cuda.current_stream()
-        if pages_dev is None and not getattr(self, "serialize_streams", False):
-            if getattr(self, "_ingest_stream", None) is None:
-                self._ingest_stream = torch.cuda.Stream(priority=-1)
-            ing = self._ingest_stream
-            ing.wait_stream(cur)
-        else:
-            ing = cur
+        # Which Huffman stage for files with restart intervals: the device kernel is 3-10x faster than the host pool on an idle chip
+        # (4-7 ms against 18-42 ms per 16 pages) and is taken for single pages; inside the saturated batch pipeline its few
+        # long-running workgroups queue behind — and hold whole CUs against — the recogniser's persistent GEMM workgroups, and the
+        # detector of the next batch waits for them: from files 33-83 pages/s depending on box and stream placement (its own
+        # high-priority stream: 33; the launch stream: 41-83), against a steady 79-82 (0.94-0.95 of resident) with the host pool.
+        # So batches default to the host pool; `pipeline.device_entropy = True` / MSOCR_JPEG_DEVICE_ENTROPY=1 force the kernel.
+        if _device_entropy is None:
+            _device_entropy = getattr(self, "device_entropy", None)
+        if _device_entropy is None and "MSOCR_JPEG_DEVICE_ENTROPY" not in os.environ and len(images) > 1:
+            _device_entropy = False
+        ing = torch.cuda.current_stream()
         with torch.cuda.stream(ing):
             if pages_dev is None and getattr(self, "device_ingest", True):
                 from . import ingest
@@ -267,8 +267,6 @@ class Pipeline:
                 else:
                     pages_dev = torch.stack([t if t is not None else torch.from_numpy(np.ascontiguousarray(a)).to(det.device)
                                              for t, a in zip(decoded, arrays)])
-        if ing is not cur:
-            cur.wait_stream(ing)
         # groups per batch.  Round 1 needed 8 groups of 2 pages to hide its host stages behind other groups' device work; with the
         # reading order on the device and Page assembly off the enqueue path, larger launch sequences win (bigger GEMM M, fewer
         # launches): 16 pages measured 44.0 / 45.4 / 45.7 pages/s at 8 / 4 / 2 groups with 4 hardware queues and 36.3 / 46.8 / 48.1
