@@ -460,6 +460,12 @@ def main():
                 sec["graphs"] = secondary_rate()
                 pipe = keep[0]
                 del det_g, rec_g
+                # the captured pipelines' private memory pools (tens of GB) go back to the driver HERE, not inside the next
+                # measurement: the run that followed this one read 33-41 pages/s whatever it measured
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             import tempfile
             from PIL import Image as _Image
             with tempfile.TemporaryDirectory(prefix="msocr_jpeg_", dir="/tmp") as td:
@@ -470,11 +476,14 @@ def main():
                     paths_dri.append(os.path.join(td, f"r{i_}.jpg"))
                     _Image.fromarray(pg_).save(paths_dri[-1], quality=90, restart_marker_blocks=16)
                 pages, a.host_pages = paths, True         # files without restart markers: entropy decode on a host thread pool (ingest.py)
+                secondary_rate(1)                         # first use of the file path (pinned buffers, pool threads), not reported
                 sec["jpeg_ingest"] = secondary_rate()
-                pages = paths_dri                         # restart interval 16 MCUs: the batch pipeline's default is still the host pool ...
+                pages = paths_dri                         # restart interval 16 MCUs: the batch pipeline's default path ...
                 sec["jpeg_ingest_restart_intervals"] = secondary_rate()
-                pipe.device_entropy = True                # ... and this forces the device Huffman stage (one thread per restart interval)
+                pipe.device_entropy = True                # ... the device Huffman stage forced (one thread per restart interval) ...
                 sec["jpeg_ingest_device_entropy"] = secondary_rate()
+                pipe.device_entropy = False               # ... and the host pool forced, for the same files
+                sec["jpeg_ingest_host_entropy"] = secondary_rate()
                 pipe.device_entropy = None
                 sec["jpeg_bytes_per_page"] = int(sum(os.path.getsize(p_) for p_ in paths_dri) / len(paths_dri))
         except Exception as e_:  # a secondary line must never take the headline down
