@@ -478,12 +478,10 @@ def main():
                 pages, a.host_pages = paths, True         # files without restart markers: entropy decode on a host thread pool (ingest.py)
                 secondary_rate(1)                         # first use of the file path (pinned buffers, pool threads), not reported
                 sec["jpeg_ingest"] = secondary_rate()
-                pages = paths_dri                         # restart interval 16 MCUs: the batch pipeline's default path ...
+                pages = paths_dri                         # restart interval 16 MCUs: the device Huffman stage (one thread per interval) ...
                 sec["jpeg_ingest_restart_intervals"] = secondary_rate()
-                pipe.device_entropy = True                # ... the device Huffman stage forced (one thread per restart interval) ...
-                sec["jpeg_ingest_device_entropy"] = secondary_rate()
-                pipe.device_entropy = False               # ... and the host pool forced, for the same files
-                sec["jpeg_ingest_host_entropy"] = secondary_rate()
+                pipe.device_entropy = False               # ... and the host pool forced for the same files
+                sec["jpeg_ingest_restart_intervals_host_entropy"] = secondary_rate()
                 pipe.device_entropy = None
                 sec["jpeg_bytes_per_page"] = int(sum(os.path.getsize(p_) for p_ in paths_dri) / len(paths_dri))
         except Exception as e_:  # a secondary line must never take the headline down
@@ -493,9 +491,8 @@ def main():
         sec["note"] = ("pages/s of the same loop, 3 steps each after the timed region: host_pages = pages handed over as host arrays "
                        "(PCIe-inclusive), graphs = EAST/TRBA(use_graphs=True), jpeg_ingest = pages read from JPEG files (quality 90, "
                        "4:2:0) through ingest.py: entropy decode on a host thread pool, reconstruction on the device; "
-                       "jpeg_ingest_restart_intervals = the same pages written with a restart interval of 16 MCUs (same path by default); "
-                       "jpeg_ingest_device_entropy = those files with the Huffman stage forced onto the device (one thread per interval): "
-                       "faster on an idle chip, erratic inside the saturated pipeline (DESIGN.md section 7)")
+                       "jpeg_ingest_restart_intervals = the same pages written with a restart interval of 16 MCUs: Huffman stage on the device, "
+                       "one thread per interval, one launch per batch; ..._host_entropy = those files with the host pool forced")
         res["secondary_lines"] = sec
     if pipe is not None:
         res["host_stage_s_last_step"] = {k: round(v, 4) for k, v in pipe.last_profile.items()}

@@ -233,16 +233,11 @@ class Pipeline:
         # pixels never exist on the host, `arrays` then only carries the shape; everything else goes through read_image
         arrays, decoded = [], []
         dec, ingest_pending = [None] * len(images), None
-        # Which Huffman stage for files with restart intervals: the device kernel is 3-10x faster than the host pool on an idle chip
-        # (4-7 ms against 18-42 ms per 16 pages) and is taken for single pages; inside the saturated batch pipeline its few
-        # long-running workgroups queue behind — and hold whole CUs against — the recogniser's persistent GEMM workgroups, and the
-        # detector of the next batch waits for them: from files 33-83 pages/s depending on box and stream placement (its own
-        # high-priority stream: 33; the launch stream: 41-83), against a steady 79-82 (0.94-0.95 of resident) with the host pool.
-        # So batches default to the host pool; `pipeline.device_entropy = True` / MSOCR_JPEG_DEVICE_ENTROPY=1 force the kernel.
+        # Which Huffman stage for files with restart intervals: ingest's policy (the device kernel unless an interval is so long that
+        # its serial chain loses to a host core; `pipeline.device_entropy = True / False` or MSOCR_JPEG_DEVICE_ENTROPY force one).
+        # From files, same box: device stage 79.5-80.1, host pool 78.2-79.2 pages/s against 83.0 resident.
         if _device_entropy is None:
             _device_entropy = getattr(self, "device_entropy", None)
-        if _device_entropy is None and "MSOCR_JPEG_DEVICE_ENTROPY" not in os.environ and len(images) > 1:
-            _device_entropy = False
         ing = torch.cuda.current_stream()
         with torch.cuda.stream(ing):
             if pages_dev is None and getattr(self, "device_ingest", True):

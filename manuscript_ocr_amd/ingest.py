@@ -224,9 +224,8 @@ def read_images_device(paths, device="cuda", device_entropy=None, defer_status=F
     core into per-slot PINNED coefficient buffers that live across batches (fresh 9 MB arrays per page made the threads serialise
     on page faults), this thread uploads and launches the reconstruction page by page as the decodes finish.
     defer_status=True -> (list, pending): the device path's one host wait — the kernel's per-page verdict — is NOT taken here; the
-    caller asks `check_pending(pending)` later (the pipeline does, when it waits for the detector anyway).  Waiting here puts the
-    ingest kernels' queueing delay behind a chip full of recogniser work on the host's critical path (measured: 41 instead of 83
-    pages/s from files on a box where it hit)."""
+    caller asks `check_pending(pending)` later (the pipeline does, when it waits for the detector anyway), so that submitting a
+    batch never waits for the device."""
     global _POOL
     import torch
     from concurrent.futures import ThreadPoolExecutor

@@ -512,12 +512,14 @@ def test_device_huffman_decode_of_restart_interval_jpegs(gpu, tmp_path):
     key = lambda p: [(w.polygon, w.detection_confidence, w.text, w.recognition_confidence) for w in p.blocks[0].words]
     good = np.array(Image.open(files[2]).convert("RGB"))
     b = pipe.predict_batch([good, flagged])
-    pipe.device_entropy = True       # batches default to the host pool: force the kernel and its late verdict
+    pipe.device_entropy = True       # the kernel and its late verdict, whatever the interval-length policy says
     a = pipe.predict_batch([files[2], str(tmp_path / "flagged.jpg")])
     assert [key(p) for p in a] == [key(p) for p in b]
+    for forced in (None, False):
+        pipe.device_entropy = forced
+        assert [key(p) for p in pipe.predict_batch([files[2], str(tmp_path / "flagged.jpg")])] == [key(p) for p in b]
     pipe.device_entropy = None
-    assert [key(p) for p in pipe.predict_batch([files[2], str(tmp_path / "flagged.jpg")])] == [key(p) for p in b]
-    assert key(pipe.predict(files[2])) == key(b[0])          # a single page takes the kernel by default
+    assert key(pipe.predict(files[2])) == key(b[0])
     # (d) bench-sized pages: 4 x 2048 x 1536, one interval per MCU row (12 KB intervals: the default policy sends them to the host
     #     decoder, device_entropy=True to the kernel — spread one interval per wave) and 16-MCU intervals (the kernel by default)
     pages = [synth.synth_page(70 + k, 2048, 1536)[0] for k in range(4)]
