@@ -11,7 +11,6 @@ recogniser once for all crops of all pages (results identical to per-page predic
 """
 import contextlib
 import gc
-import os
 import time
 from typing import List, Optional, Union
 
