@@ -107,6 +107,7 @@ def _tall_pays(H):
 # (precision="fp32" default); taken where it is cheaper than the tall form for the map width: 36 * ceil(W/4) < 24 * ceil(W/2).
 # MSOCR_WINO_SQUARE=0 keeps the tall form.
 WINOGRAD_SQUARE = int(os.environ.get("MSOCR_WINO_SQUARE", "1"))
+WINOGRAD_SQUARE_MIN_CIN = int(os.environ.get("MSOCR_WINO_SQUARE_MIN_CIN", "128"))
 
 
 def _square_pays(W):
@@ -205,7 +206,7 @@ def attach_winograd(w, split=None, square=True):
     w._msocr_wino42 = u42.to(w.device)
     if (SPLIT_BF16X3 if split is None else split) and Cin % 32 == 0 and Cout % 64 == 0:
         w._msocr_wino42_split = split_planes_ktile(u42, 24, Cout).to(w.device)  # [3][24][Cin/32][Cout][32] bf16
-        if WINOGRAD_SQUARE and square:  # square=False: the caller keeps this layer on the tall form (half the rounding error)
+        if WINOGRAD_SQUARE and square and Cin >= WINOGRAD_SQUARE_MIN_CIN:  # square=False: the caller keeps this layer on the tall form (half the rounding error)
             u44 = torch.empty((36, Cout, Cin), dtype=torch.float32)
             nat.check(nat.lib().msocr_winograd44_weights_host(wh.data_ptr(), Cout, Cin, u44.data_ptr()), "winograd44_weights_host")
             w._msocr_wino44_split = split_planes_ktile(u44, 36, Cout).to(w.device)  # [3][36][Cin/32][Cout][32] bf16

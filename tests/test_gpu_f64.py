@@ -68,16 +68,18 @@ def test_east_forward_device_vs_f64_no_worse_than_2x_the_oracle_f32(hw, pages):
         assert ex_g < 1e-4, ex_g
 
 
-def test_trba_batch_H_device_vs_f64_no_worse_than_2x_the_oracle_f32():
+@pytest.mark.parametrize("seed", [5, 11, 23])
+def test_trba_batch_H_device_vs_f64_no_worse_than_2x_the_oracle_f32(seed):
+    """Three weight sets: the 2x bound must not hinge on one draw (the square Winograd form sits at 1.6-1.9 of it)."""
     _need_gpu()
     from manuscript_ocr_amd.recognizers._trba.net import TrbaNet
     from oracle import trba_model as otm
-    sd = synth.trba_state_dict(194, 256, seed=5)
+    sd = synth.trba_state_dict(194, 256, seed=seed)
     net32 = otm.TRBANet(194, 256)
     net32.load_state_dict(sd, strict=True)
     net32.eval()
     net64 = copy.deepcopy(net32).double()
-    canv = synth.synth_crops(9, 32, 32, 100)
+    canv = synth.synth_crops(9 + seed, 32, 32, 100)
     x = torch.from_numpy(((canv.astype(np.float32) - 127.5) * np.float32(1 / 127.5)).transpose(0, 3, 1, 2).copy())
     with torch.no_grad():
         f32_, f64_ = net32.cnn(x).permute(0, 2, 3, 1).numpy(), net64.cnn(x.double()).permute(0, 2, 3, 1).numpy()
@@ -86,7 +88,7 @@ def test_trba_batch_H_device_vs_f64_no_worse_than_2x_the_oracle_f32():
     cd = torch.from_numpy(canv).cuda()
     f_dev = net.cnn(cd).float().cpu().numpy()
     h_dev = net.encode(cd)[0].float().cpu().numpy()
-    ef_d, ef_r = _report("TRBA SE-ResNet31 features (32 crops)", f_dev.reshape(f64_.shape), f32_, f64_)
-    eh_d, eh_r = _report("TRBA batch_H (32 crops)", h_dev, h32, h64)
+    ef_d, ef_r = _report(f"TRBA SE-ResNet31 features (32 crops, seed {seed})", f_dev.reshape(f64_.shape), f32_, f64_)
+    eh_d, eh_r = _report(f"TRBA batch_H (32 crops, seed {seed})", h_dev, h32, h64)
     assert ef_d <= 2.0 * ef_r, (ef_d, ef_r)
     assert eh_d <= 2.0 * eh_r, (eh_d, eh_r)
