@@ -103,11 +103,15 @@ def _tall_pays(H):
 
 
 # Square form F(4,3) x F(4,3) on the points {0, +-3/2, +-2/3, inf} (csrc/winograd.hip, wino44_*; round 4): 36 points per 4x4 outputs =
-# 2.25 multiplies and workspace words per output instead of 3, at the tall form's rounding error.  Split-operand GEMMs only
-# (precision="fp32" default); taken where it is cheaper than the tall form for the map width: 36 * ceil(W/4) < 24 * ceil(W/2).
-# MSOCR_WINO_SQUARE=0 keeps the tall form.
+# 2.25 multiplies and workspace words per output instead of 3.  Split-operand GEMMs only (precision="fp32" default); taken where it is
+# cheaper than the tall form for the map width: 36 * ceil(W/4) < 24 * ceil(W/2).  MSOCR_WINO_SQUARE=0 keeps the tall form.
+# Which layers: per layer the square form's rounding error is 1.1-1.3x the tall form's on the textbook points and 2.2-2.5x the tall
+# form's on the new points; end to end (tests/test_gpu_f64.py, device error against f64 relative to the reference's own f32 error,
+# bound 2.0, three weight sets) the recogniser reads 1.47-1.60 all tall, 1.79-1.91 with the square form on its Cin = 512 layers
+# (+4.0 % pages/s on one box: 81.6 -> 84.9) and 1.71-2.24 with it on every eligible layer (+5.9 %: 86.4) — the default is the
+# largest set that holds the bound on all three: Cin >= 512 (MSOCR_WINO_SQUARE_MIN_CIN=256 takes the rest).
 WINOGRAD_SQUARE = int(os.environ.get("MSOCR_WINO_SQUARE", "1"))
-WINOGRAD_SQUARE_MIN_CIN = int(os.environ.get("MSOCR_WINO_SQUARE_MIN_CIN", "128"))
+WINOGRAD_SQUARE_MIN_CIN = int(os.environ.get("MSOCR_WINO_SQUARE_MIN_CIN", "512"))
 
 
 def _square_pays(W):

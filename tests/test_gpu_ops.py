@@ -252,6 +252,7 @@ def test_winograd44_square_form_vs_tall_and_f64(ops, case, monkeypatch):
     itself 4.7x (tools/winograd_points.py) — partial tiles on both axes, residual, ReLU, TRBA's 4 x 13 / 8 x 25 / 16 x 50 maps and an
     EAST-sized one."""
     monkeypatch.setattr(ops, "_tall_pays", lambda H: True)
+    monkeypatch.setattr(ops, "WINOGRAD_SQUARE_MIN_CIN", 128)   # the kernels at every width (the product's default: Cin >= 512)
     N, H, W, Cin, Cout, relu, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]) + 1)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -357,8 +358,9 @@ def test_conv_pool2_unfused_paths(ops):
         assert a.shape == (2, H // 2, W // 2, 64) and torch.equal(a, c)
 
 
-def test_winograd_weight_transform_matches_definition(ops):
+def test_winograd_weight_transform_matches_definition(ops, monkeypatch):
     """U = G g G^T evaluated in f64 (msocr_winograd_weights_host) for every (xi, nu)."""
+    monkeypatch.setattr(ops, "WINOGRAD_SQUARE_MIN_CIN", 128)
     g = torch.Generator().manual_seed(9)
     w = torch.randn(64, 128, 3, 3, generator=g)
     wk = ops.attach_winograd(_w_khwc(w, torch.float32))
