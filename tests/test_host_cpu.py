@@ -435,20 +435,25 @@ def test_vectorised_crop_descriptors_equal_the_loop():
 
 
 def test_winograd_weight_transforms_host():
-    """The two load-time weight transforms are HOST functions of the C ABI (f64, rounded once): U = G g G^T for F(2x2,3x3) and
-    U = G6 g G4^T for the tall form F(4,3) x F(2,3), checked against their definitions without a GPU."""
+    """The load-time weight transforms are HOST functions of the C ABI (f64, rounded once): U = G g G^T for F(2x2,3x3), U = G6 g G4^T
+    for the tall form F(4,3) x F(2,3) and U = G6 g G6^T for the square form, G6 = the Cook-Toom matrix of F(4,3) on the interpolation
+    points {0, 3/2, -3/2, 2/3, -2/3, inf} (round 4), checked against their definitions without a GPU."""
     from manuscript_ocr_amd import _native as nat
     L = nat.lib()
     rng = np.random.default_rng(11)
     Cout, Cin = 32, 16
     w = rng.standard_normal((Cout, 3, 3, Cin)).astype(np.float32)  # [Cout][KH][KW][Cin]
     G4 = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float64)
-    G6 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                   [0, 0, 1]], np.float64)
-    for fn, Gh, npts in ((L.msocr_winograd_weights_host, G4, 16), (L.msocr_winograd42_weights_host, G6, 24)):
+    pts = [0.0, 1.5, -1.5, 2 / 3, -2 / 3]
+    G6 = np.zeros((6, 3), np.float64)
+    for j, a in enumerate(pts):   # G[j] = [1, a, a^2] / prod_{l != j}(a_j - a_l); the point at infinity: [0, 0, 1]
+        G6[j] = np.array([1.0, a, a * a]) / np.prod([a - b for l, b in enumerate(pts) if l != j])
+    G6[5, 2] = 1.0
+    for fn, Gh, Gw, npts in ((L.msocr_winograd_weights_host, G4, G4, 16), (L.msocr_winograd42_weights_host, G6, G4, 24),
+                             (L.msocr_winograd44_weights_host, G6, G6, 36)):
         u = np.empty((npts, Cout, Cin), np.float32)
         assert fn(w.ctypes.data, Cout, Cin, u.ctypes.data) == 0
-        exp = np.einsum("xk,oklc,nl->xnoc", Gh, w.astype(np.float64), G4).reshape(npts, Cout, Cin)
+        exp = np.einsum("xk,oklc,nl->xnoc", Gh, w.astype(np.float64), Gw).reshape(npts, Cout, Cin)
         assert np.abs(u.astype(np.float64) - exp).max() <= 1.2e-7 * np.abs(exp).max()
     assert L.msocr_winograd42_weights_host(None, Cout, Cin, None) != 0
 
