@@ -43,8 +43,9 @@ def test_crop_resize_pad_bit_exact_vs_oracle(gpu):
             assert np.array_equal(got[k], exp), (k, boxes[k], ih, iw, np.abs(got[k].astype(int) - exp.astype(int)).max())
 
 
-def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5, target_wh=None):
-    """The reference path on the CPU: infer.py:319-363 + _pipeline.py:100-162 + TRBA.predict (beam defaults)."""
+def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5, target_wh=None, max_text=None):
+    """The reference path on the CPU: infer.py:319-363 + _pipeline.py:100-162 + TRBA.predict (beam defaults).  max_text: run the CPU
+    recogniser on the first max_text crops only (the others get text "?unchecked"): boxes, confidences and order are still complete."""
     from oracle import east_post as P
     from oracle import imgproc
     from oracle import lanms as L
@@ -55,11 +56,13 @@ def _oracle_pipeline(page, score, geo, trba_net, itos, cfg, min_text_size=5, tar
     polys = [q[:8].reshape(4, 2).tolist() for q in quads]
     order, kept, crops = G.order_and_crop(polys, page, min_text_size)
     res = []
-    for c0 in range(0, len(crops), 32):
+    n_text = len(crops) if max_text is None else min(len(crops), max_text // 32 * 32)
+    for c0 in range(0, n_text, 32):
         x = torch.from_numpy(np.stack([imgproc.trba_preprocess(c, cfg["img_h"], cfg["img_w"]) for c in crops[c0:c0 + 32]]))
         with torch.no_grad():
             lg, ids = trba_net(x, max_len=cfg["max_len"], mode="beam", beam_size=8, alpha=0.9, temperature=1.7)
         res += otm.texts_and_confidences(lg, ids, itos, 0, 2, None)
+    res += [{"text": "?unchecked", "confidence": None, "logits0": None}] * (len(crops) - n_text)
     words = [{"polygon": polys[wi], "det": float(quads[wi][8]), "text": None, "rec": None} for wi in order]
     for pos, r in zip(kept, res):
         words[pos]["text"], words[pos]["rec"], words[pos]["logits0"] = r["text"], r["confidence"], r["logits0"]

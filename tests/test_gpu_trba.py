@@ -251,7 +251,8 @@ DECODER_LOGIT_RTOL = 2e-4
 @pytest.mark.parametrize("mode", ["greedy", "beam"])
 def test_trba_random_weights_decode_parity(env, mode):
     """ALL-RANDOM weights (synth.trba_state_dict: x6 recurrent gain, every character an arg-max over near-Gaussian logits —
-    the most rounding-sensitive decoder we can build), 256 crops, the reference's 32-row chunks.  Every row must reproduce
+    the most rounding-sensitive decoder we can build), 160 crops (256 until round 4: the driver's GPU tier allows the suite 900 s, and
+    bench.py's cpu_baseline runs the same comparison on 256), the reference's 32-row chunks.  Every row must reproduce
     the oracle's ids at every generated step; the only admitted difference is at the FIRST differing step and only where the
     oracle's own decision margin there is below TIE_TOL (conftest.compare_decodes).  Logits up to that step: this decoder is
     chaotic (x6 recurrent gain, 25-26 chained steps), so a fixed tolerance would be "whatever passed"; the bound is CALIBRATED
@@ -263,7 +264,7 @@ def test_trba_random_weights_decode_parity(env, mode):
     from conftest import compare_decodes
     from manuscript_ocr_amd.recognizers import TRBA
     otm = env
-    N = 256
+    N = 160
     rec = TRBA(state_dict=synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED),
                config={"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}, device="cuda")
     ids, trun, conf, lg, exp, cal = _random_weight_case(otm, RANDOM_WEIGHT_SEED, N, mode, rec)
@@ -328,7 +329,8 @@ def test_trba_shipped_config_32x128_maxlen40(env, mode):
 
 
 def test_trba_random_weights_three_way(env, monkeypatch):
-    """The same 256 all-random-weight crops through (a) the default path (Winograd 3x3 layers, matrix-core beam kernel),
+    """The same 96 all-random-weight crops (three reference chunks; 256 in rounds 1-3 — the driver's GPU tier allows the whole suite
+    900 s and each variant re-runs the CPU oracle's calibration) through (a) the default path (Winograd 3x3 layers, matrix-core beam kernel),
     (b) direct convolutions only (MSOCR_WINOGRAD_MIN_CIN=0), (c) the VALU beam kernel (MSOCR_BEAM_MFMA=0): each against the
     oracle under the near-tie rule, and pairwise: rows that are identical to the oracle in two variants are identical to
     each other, so the variants can only differ on the oracle's near-tie rows."""
@@ -336,7 +338,7 @@ def test_trba_random_weights_three_way(env, monkeypatch):
     from manuscript_ocr_amd import ops
     from manuscript_ocr_amd.recognizers import TRBA
     otm = env
-    N, cfg = 256, {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
+    N, cfg = 96, {"img_h": 32, "img_w": 100, "max_len": 25, "hidden_size": 256}
     sd = synth.trba_state_dict(194, 256, seed=RANDOM_WEIGHT_SEED)
     results = {}
     rec_w = TRBA(state_dict=sd, config=cfg, device="cuda")
@@ -544,7 +546,7 @@ def test_random_span_layouts_match_the_full_length_decode(env, monkeypatch):
     (128, 194, 8, "greedy"), (128, 194, 8, "beam"),   # hidden_size 128
     (512, 194, 8, "beam"), (512, 194, 1, "greedy"),   # hidden_size 512
     (256, 400, 8, "beam"), (256, 400, 1, "greedy"),   # a charset above 256 tokens
-    (256, 194, 12, "beam"), (256, 194, 16, "beam"),   # beam widths above 8 (the reference's Optuna script sweeps 2..12)
+    (256, 194, 12, "beam"),                           # a beam width above 8 (the reference's Optuna script sweeps 2..12)
     (256, 194, 3, "beam"),                            # a narrow beam on the matrix-core kernel (unused beam slots)
 ])
 def test_trba_shapes_beyond_the_default_kernels(env, hidden, V, beam, mode, tmp_path):
