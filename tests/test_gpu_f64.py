@@ -28,19 +28,20 @@ def _report(what, dev, ref32, ref64):
     return e_dev, e_ref
 
 
-@pytest.mark.parametrize("hw,pages", [((256, 192), 2), ((1536, 2048), 1)])
-def test_east_forward_device_vs_f64_no_worse_than_2x_the_oracle_f32(hw, pages):
+@pytest.mark.parametrize("hw,pages,seed", [((256, 192), 2, 20260128), ((256, 192), 2, 7), ((256, 192), 2, 99), ((1536, 2048), 1, 20260128)])
+def test_east_forward_device_vs_f64_no_worse_than_2x_the_oracle_f32(hw, pages, seed):
+    """Three weight sets at the small size (the bound must not hinge on one draw), the bench's size once."""
     _need_gpu()
     from manuscript_ocr_amd.detectors._east.net import EastNet
     from oracle import east_model as oem
     from oracle import imgproc
-    sd = synth.east_state_dict(seed=20260128)
+    sd = synth.east_state_dict(seed=seed)
     net32 = oem.EASTNet()
     net32.load_state_dict(sd)
     net32.eval()
     net64 = copy.deepcopy(net32).double()
     H, W = hw
-    pg = np.stack([synth.synth_page(31 + k, H, W)[0] for k in range(pages)])
+    pg = np.stack([synth.synth_page(31 + k + seed % 1000, H, W)[0] for k in range(pages)])
     x = torch.from_numpy(np.concatenate([imgproc.east_preprocess(p, W, H) for p in pg]))
     with torch.no_grad():
         r32 = net32(x)
